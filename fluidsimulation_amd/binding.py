@@ -1,0 +1,312 @@
+"""ctypes binding of libflip_hip.so (include/flip_hip.h).
+
+This is plumbing for the tests and the benchmark: it moves numpy arrays across the C ABI and nothing
+else.  There is no fallback: if the shared library is missing, or no HIP device is present, the calls
+raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflip_hip.so")
+
+
+class FlipError(RuntimeError):
+    pass
+
+
+class GridDesc(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("ox", C.c_int32), ("oy", C.c_int32),
+                ("oz", C.c_int32), ("dx", C.c_float), ("phi_fluid_bg", C.c_float), ("phi_solid_bg", C.c_float),
+                ("rest_density", C.c_float)]
+
+
+class PcgInfo(C.Structure):
+    _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("rows", C.c_int32),
+                ("active_chunks", C.c_int32), ("rel_residual_2", C.c_double), ("rhs_norm_2", C.c_double),
+                ("seconds", C.c_double), ("spmv_seconds", C.c_double), ("spmv_launches", C.c_int32),
+                ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# enum flip_field: name -> (id, dtype)
+FIELDS = {
+    "phi_fluid": (0, np.float32), "phi_solid": (1, np.float32),
+    "vel_u": (2, np.float64), "vel_v": (3, np.float64), "vel_w": (4, np.float64),
+    "prev_u": (5, np.float64), "prev_v": (6, np.float64), "prev_w": (7, np.float64),
+    "diff_u": (8, np.float64), "diff_v": (9, np.float64), "diff_w": (10, np.float64),
+    "disp_x": (11, np.float64), "disp_y": (12, np.float64), "disp_z": (13, np.float64),
+    "weight_u": (14, np.float32), "weight_v": (15, np.float32), "weight_w": (16, np.float32),
+    "fluid_weight_u": (17, np.float32), "fluid_weight_v": (18, np.float32), "fluid_weight_w": (19, np.float32),
+    "density": (20, np.float32), "pressure": (21, np.float64),
+    "valid_u": (22, np.uint8), "valid_v": (23, np.uint8), "valid_w": (24, np.uint8),
+    "active": (25, np.uint8), "label": (26, np.uint8), "row_index": (27, np.int32), "band": (28, np.uint8),
+    "obj_weight_u": (29, np.float32), "obj_weight_v": (30, np.float32), "obj_weight_w": (31, np.float32),
+    "phi_object": (32, np.float32),
+}
+
+SOLVE_DIVERGENCE, SOLVE_DENSITY = 0, 1
+PRECOND_JACOBI, PRECOND_MULTIGRID = 0, 1
+
+# every symbol include/flip_hip.h declares
+EXPORTS = [
+    "flip_ctx_create", "flip_ctx_destroy", "flip_last_error", "flip_synchronize", "flip_get_desc",
+    "flip_particles_upload", "flip_particles_download", "flip_particles_count", "flip_bin_particles",
+    "flip_binning_download", "flip_field_upload", "flip_field_download", "flip_field_bytes", "flip_p2g", "flip_g2p",
+    "flip_apply_displacements", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
+    "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_index_cells", "flip_face_fractions",
+    "flip_density", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
+    "flip_set_null_row_policy", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_project_velocity",
+    "flip_project_displacement",
+]
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """Load libflip_hip.so.  Raises FlipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise FlipError(f"{path} not found: build it with `make -C fluidsimulation_amd/csrc` "
+                        "(there is no CPU fallback for the HIP path)")
+    lib = C.CDLL(path)
+    vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+    P = C.POINTER
+    sig = {
+        "flip_ctx_create": (C.c_int, [P(GridDesc), C.c_int, vp, P(vp)]),
+        "flip_ctx_destroy": (None, [vp]),
+        "flip_last_error": (C.c_char_p, [vp]),
+        "flip_synchronize": (C.c_int, [vp]),
+        "flip_get_desc": (C.c_int, [vp, P(GridDesc)]),
+        "flip_particles_upload": (C.c_int, [vp, i64, vp, vp, vp]),
+        "flip_particles_download": (C.c_int, [vp, vp, vp]),
+        "flip_particles_count": (i64, [vp]),
+        "flip_bin_particles": (C.c_int, [vp, P(i64)]),
+        "flip_binning_download": (C.c_int, [vp, vp, vp, vp]),
+        "flip_field_upload": (C.c_int, [vp, C.c_int, vp]),
+        "flip_field_download": (C.c_int, [vp, C.c_int, vp]),
+        "flip_field_bytes": (i64, [vp, C.c_int]),
+        "flip_p2g": (C.c_int, [vp]),
+        "flip_g2p": (C.c_int, [vp, f32]),
+        "flip_apply_displacements": (C.c_int, [vp]),
+        "flip_mark_valid_from_active": (C.c_int, [vp]),
+        "flip_extrapolate": (C.c_int, [vp, C.c_int]),
+        "flip_add_forces": (C.c_int, [vp, f32]),
+        "flip_update_prev": (C.c_int, [vp]),
+        "flip_update_diff": (C.c_int, [vp]),
+        "flip_velocity_max": (C.c_int, [vp, P(f64)]),
+        "flip_index_cells": (C.c_int, [vp, P(i32)]),
+        "flip_face_fractions": (C.c_int, [vp]),
+        "flip_density": (C.c_int, [vp, P(i64)]),
+        "flip_solid_object_set": (C.c_int, [vp, vp, f32, vp, vp, vp]),
+        "flip_solid_object_velocity": (C.c_int, [vp, P(f64)]),
+        "flip_build_system": (C.c_int, [vp, C.c_int, f32]),
+        "flip_set_null_row_policy": (C.c_int, [vp, C.c_int]),
+        "flip_system_download": (C.c_int, [vp, vp, vp, vp]),
+        "flip_pcg_solve": (C.c_int, [vp, f64, i32, C.c_int, P(PcgInfo)]),
+        "flip_apply_operator": (C.c_int, [vp, vp, vp]),
+        "flip_set_profiling": (C.c_int, [vp, C.c_int]),
+        "flip_project_velocity": (C.c_int, [vp, f32]),
+        "flip_project_displacement": (C.c_int, [vp, f32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class FlipContext:
+    """One device context: the dense MAC grid of a FluidDomain plus its ParticleSet, resident in HBM."""
+
+    def __init__(self, desc: dict, device: int = 0, stream: int | None = None):
+        self.lib = load_library()
+        self.desc = GridDesc(**desc)
+        self.dims = (desc["nx"], desc["ny"], desc["nz"])
+        self.shape = (desc["nz"], desc["ny"], desc["nx"])
+        self.n_cells = desc["nx"] * desc["ny"] * desc["nz"]
+        h = C.c_void_p()
+        rc = self.lib.flip_ctx_create(C.byref(self.desc), device, C.c_void_p(stream or 0), C.byref(h))
+        if rc != 0:
+            raise FlipError(self.lib.flip_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.flip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FlipError(self.lib.flip_last_error(self.h).decode())
+
+    # ---- particles ----
+    def upload_particles(self, pos, vel, mass):
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        vel = np.ascontiguousarray(vel, dtype=np.float64)
+        mass = np.ascontiguousarray(mass, dtype=np.float32)
+        n = pos.shape[0]
+        assert pos.shape == (n, 3) and vel.shape == (n, 3) and mass.shape == (n,)
+        self._check(self.lib.flip_particles_upload(self.h, n, _ptr(pos), _ptr(vel), _ptr(mass)))
+
+    def download_particles(self):
+        n = self.lib.flip_particles_count(self.h)
+        pos = np.empty((n, 3), dtype=np.float64)
+        vel = np.empty((n, 3), dtype=np.float64)
+        self._check(self.lib.flip_particles_download(self.h, _ptr(pos), _ptr(vel)))
+        return pos, vel
+
+    def bin_particles(self, want_outside: bool = True) -> int:
+        out = C.c_int64(0)
+        self._check(self.lib.flip_bin_particles(self.h, C.byref(out) if want_outside else None))
+        return out.value
+
+    def download_binning(self):
+        n = self.lib.flip_particles_count(self.h)
+        cell_id = np.empty(n, dtype=np.int32)
+        cell_start = np.empty(self.n_cells + 1, dtype=np.int32)
+        perm = np.empty(n, dtype=np.int32)
+        self._check(self.lib.flip_binning_download(self.h, _ptr(cell_id), _ptr(cell_start), _ptr(perm)))
+        return cell_id, cell_start, perm
+
+    # ---- fields ----
+    def upload(self, name: str, arr):
+        fid, dt = FIELDS[name]
+        a = np.ascontiguousarray(arr, dtype=dt)
+        assert a.size == self.n_cells, (name, a.shape, self.shape)
+        self._check(self.lib.flip_field_upload(self.h, fid, _ptr(a)))
+
+    def download(self, name: str):
+        fid, dt = FIELDS[name]
+        a = np.empty(self.shape, dtype=dt)
+        self._check(self.lib.flip_field_download(self.h, fid, _ptr(a)))
+        return a
+
+    # ---- stages ----
+    def p2g(self):
+        self._check(self.lib.flip_p2g(self.h))
+
+    def g2p(self, ratio: float):
+        self._check(self.lib.flip_g2p(self.h, ratio))
+
+    def apply_displacements(self):
+        self._check(self.lib.flip_apply_displacements(self.h))
+
+    def mark_valid_from_active(self):
+        self._check(self.lib.flip_mark_valid_from_active(self.h))
+
+    def extrapolate(self, iterations: int = 2):
+        self._check(self.lib.flip_extrapolate(self.h, iterations))
+
+    def add_forces(self, dt: float):
+        self._check(self.lib.flip_add_forces(self.h, dt))
+
+    def update_prev(self):
+        self._check(self.lib.flip_update_prev(self.h))
+
+    def update_diff(self):
+        self._check(self.lib.flip_update_diff(self.h))
+
+    def velocity_max(self):
+        out = (C.c_double * 3)()
+        self._check(self.lib.flip_velocity_max(self.h, out))
+        return np.array(out[:], dtype=np.float64)
+
+    def index_cells(self) -> int:
+        n = C.c_int32(0)
+        self._check(self.lib.flip_index_cells(self.h, C.byref(n)))
+        return n.value
+
+    def face_fractions(self):
+        self._check(self.lib.flip_face_fractions(self.h))
+
+    def density(self, want_count: bool = True) -> int:
+        n = C.c_int64(0)
+        self._check(self.lib.flip_density(self.h, C.byref(n) if want_count else None))
+        return n.value
+
+    def set_solid_object(self, phi_object, bg, com, minv, vel):
+        if phi_object is None:
+            self._check(self.lib.flip_solid_object_set(self.h, None, 0.0, None, None, None))
+            return
+        phi = np.ascontiguousarray(phi_object, dtype=np.float32)
+        com = np.ascontiguousarray(com, dtype=np.float64)
+        minv = np.ascontiguousarray(minv, dtype=np.float64)
+        vel = np.ascontiguousarray(vel, dtype=np.float64)
+        assert phi.size == self.n_cells and com.size == 3 and minv.size == 6 and vel.size == 6
+        self._check(self.lib.flip_solid_object_set(self.h, _ptr(phi), bg, _ptr(com), _ptr(minv), _ptr(vel)))
+
+    def solid_object_velocity(self):
+        out = (C.c_double * 6)()
+        self._check(self.lib.flip_solid_object_velocity(self.h, out))
+        return np.array(out[:], dtype=np.float64)
+
+    def build_system(self, kind: int, dt: float):
+        self._check(self.lib.flip_build_system(self.h, kind, dt))
+
+    def set_null_row_policy(self, drop: bool):
+        self._check(self.lib.flip_set_null_row_policy(self.h, 1 if drop else 0))
+
+    def download_system(self):
+        off = np.empty((6,) + self.shape, dtype=np.float64)
+        diag = np.empty(self.shape, dtype=np.float64)
+        rhs = np.empty(self.shape, dtype=np.float64)
+        self._check(self.lib.flip_system_download(self.h, _ptr(off), _ptr(diag), _ptr(rhs)))
+        return off, diag, rhs
+
+    def pcg_solve(self, tol: float = 1e-15, max_iter: int = 0, precond: int = PRECOND_JACOBI) -> dict:
+        info = PcgInfo()
+        self._check(self.lib.flip_pcg_solve(self.h, tol, max_iter, precond, C.byref(info)))
+        return info.as_dict()
+
+    def apply_operator(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.size == self.n_cells
+        y = np.empty(self.shape, dtype=np.float64)
+        self._check(self.lib.flip_apply_operator(self.h, _ptr(x), _ptr(y)))
+        return y
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.flip_set_profiling(self.h, 1 if on else 0))
+
+    def project_velocity(self, dt: float):
+        self._check(self.lib.flip_project_velocity(self.h, dt))
+
+    def project_displacement(self, dt: float):
+        self._check(self.lib.flip_project_displacement(self.h, dt))
+
+    def synchronize(self):
+        self._check(self.lib.flip_synchronize(self.h))
+
+    # ---- convenience ----
+    def upload_scene(self, sc):
+        self.upload("phi_solid", sc.phi_solid)
+        self.upload("phi_fluid", sc.phi_fluid)
+        self.upload_particles(sc.pos, sc.vel, sc.mass)
+        if sc.phi_object is not None:
+            self.set_solid_object(sc.phi_object, sc.phi_object_bg, sc.object_com, sc.object_minv, sc.object_vel)

@@ -1,0 +1,371 @@
+// flip_ctx.hip -- context life cycle, dense-field and particle transfers, the integer scan.
+#include "flip_internal.h"
+
+#include <algorithm>
+
+static std::string g_create_error;
+
+int flip_fail(flip_ctx *ctx, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s (%s:%d)", what, file, line);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return 1;
+}
+int flip_fail_hip(flip_ctx *ctx, hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s (%s:%d)", (int)e, hipGetErrorString(e), what, file, line);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return 2;
+}
+
+extern "C" const char *flip_last_error(const flip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+template <class T>
+static hipError_t dalloc(T **p, int64_t count) {
+    hipError_t e = hipMalloc((void **)p, (size_t)(count > 0 ? count : 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemset(*p, 0, (size_t)(count > 0 ? count : 1) * sizeof(T));
+}
+template <class T>
+static void dfree(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+static void free_particles(flip_ctx *c) {
+    for (int b = 0; b < 2; ++b) {
+        for (int a = 0; a < 6; ++a) dfree(c->p[b][a]);
+        dfree(c->mass[b]);
+        dfree(c->pid[b]);
+    }
+    dfree(c->cell_id);
+    dfree(c->slot_src);
+    dfree(c->slot_key);
+    dfree(c->stage);
+    c->cap = 0;
+}
+
+extern "C" void flip_ctx_destroy(flip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_particles(c);
+    dfree(c->cell_start); dfree(c->cell_fill); dfree(c->scan_tmp);
+    dfree(c->phi_fluid); dfree(c->phi_solid); dfree(c->phi_obj);
+    for (int b = 0; b < 4; ++b)
+        for (int a = 0; a < 3; ++a) dfree(c->vel[b][a]);
+    for (int a = 0; a < 3; ++a) {
+        dfree(c->disp[a]); dfree(c->wgt[a]); dfree(c->fwgt[a]); dfree(c->owgt[a]); dfree(c->term[a]);
+        dfree(c->valid[0][a]); dfree(c->valid[1][a]);
+    }
+    for (int a = 0; a < 6; ++a) dfree(c->J[a]);
+    dfree(c->density); dfree(c->active); dfree(c->active_back); dfree(c->label); dfree(c->band);
+    dfree(c->seed); dfree(c->tmp_u8); dfree(c->row_index);
+    dfree(c->flags); dfree(c->diag); dfree(c->invdiag); dfree(c->rhs);
+    dfree(c->x); dfree(c->r); dfree(c->z); dfree(c->pv[0]); dfree(c->pv[1]); dfree(c->ap);
+    dfree(c->chunk_flag); dfree(c->chunk_list); dfree(c->d_counts); dfree(c->partial); dfree(c->scal);
+    dfree(c->d_vmax);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *stream, flip_ctx **out) {
+    flip_ctx *ctx = nullptr; // so that the macros record into the creation error
+    FLIP_REQUIRE(desc && out, "flip_ctx_create: null argument");
+    FLIP_REQUIRE(desc->nx > 0 && desc->ny > 0 && desc->nz > 0, "flip_ctx_create: empty box");
+    FLIP_REQUIRE((int64_t)desc->nx * desc->ny * desc->nz < (int64_t)2000000000, "flip_ctx_create: box too large for 32-bit cell ids");
+    FLIP_REQUIRE(desc->dx > 0.f, "flip_ctx_create: dx must be positive");
+    int ndev = 0;
+    FLIP_CHECK(hipGetDeviceCount(&ndev));
+    FLIP_REQUIRE(ndev > 0, "flip_ctx_create: no HIP device (this library has no CPU path)");
+    FLIP_REQUIRE(device >= 0 && device < ndev, "flip_ctx_create: device index out of range");
+    FLIP_CHECK(hipSetDevice(device));
+
+    flip_ctx *c = new flip_ctx();
+    c->g = *desc;
+    c->B = (int64_t)desc->nx * desc->ny * desc->nz;
+    c->n_chunks = flip_grid_blocks(c->B);
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    const int64_t B = c->B;
+
+    hipError_t e = hipSuccess;
+#define A(ptr, count)                                  \
+    if (e == hipSuccess) e = dalloc(&(ptr), (count));
+    A(c->cell_start, B + 2) A(c->cell_fill, B + 1)
+    A(c->phi_fluid, B) A(c->phi_solid, B) A(c->phi_obj, B)
+    for (int b = 0; b < 4; ++b)
+        for (int a = 0; a < 3; ++a) A(c->vel[b][a], B)
+    for (int a = 0; a < 3; ++a) {
+        A(c->disp[a], B) A(c->wgt[a], B) A(c->fwgt[a], B) A(c->owgt[a], B) A(c->term[a], B)
+        A(c->valid[0][a], B) A(c->valid[1][a], B)
+    }
+    for (int a = 0; a < 6; ++a) A(c->J[a], B)
+    A(c->density, B) A(c->active, B) A(c->active_back, B) A(c->label, B) A(c->band, B) A(c->seed, B)
+    A(c->tmp_u8, B) A(c->row_index, B + 1)
+    A(c->flags, B) A(c->diag, B) A(c->invdiag, B) A(c->rhs, B)
+    A(c->x, B) A(c->r, B) A(c->z, B) A(c->pv[0], B) A(c->pv[1], B) A(c->ap, B)
+    A(c->chunk_flag, c->n_chunks + 1) A(c->chunk_list, c->n_chunks + 1)
+    A(c->d_counts, 8) A(c->partial, 16 * FLIP_MAX_PCG_BLOCKS) A(c->scal, 1) A(c->d_vmax, 3 * FLIP_MAX_PCG_BLOCKS)
+#undef A
+    if (e != hipSuccess) {
+        flip_ctx_destroy(c);
+        return flip_fail_hip(nullptr, e, "hipMalloc of the dense fields", __FILE__, __LINE__);
+    }
+    // phi fields start at their backgrounds ("no fluid", "all open") until uploaded
+    {
+        std::vector<float> bgf((size_t)B, desc->phi_fluid_bg);
+        e = hipMemcpy(c->phi_fluid, bgf.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            std::fill(bgf.begin(), bgf.end(), desc->phi_solid_bg);
+            e = hipMemcpy(c->phi_solid, bgf.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess) {
+            flip_ctx_destroy(c);
+            return flip_fail_hip(nullptr, e, "initialising the level sets", __FILE__, __LINE__);
+        }
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+        int nb = prop.multiProcessorCount * 4;
+        nb = (nb / 8) * 8;
+        if (nb < 8) nb = 8;
+        if (nb > FLIP_MAX_PCG_BLOCKS) nb = FLIP_MAX_PCG_BLOCKS;
+        c->pcg_blocks = nb;
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" int flip_synchronize(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int flip_get_desc(const flip_ctx *ctx, flip_grid_desc *out) {
+    if (!ctx || !out) return 1;
+    *out = ctx->g;
+    return 0;
+}
+extern "C" int flip_set_profiling(flip_ctx *ctx, int enabled) {
+    FLIP_REQUIRE(ctx, "null context");
+    ctx->profiling = enabled != 0;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense fields
+
+static int field_ptr(flip_ctx *c, int field, void **ptr, int *elem) {
+    void *p = nullptr;
+    int es = 0;
+    switch (field) {
+    case FLIP_F_PHI_FLUID: p = c->phi_fluid; es = 4; break;
+    case FLIP_F_PHI_SOLID: p = c->phi_solid; es = 4; break;
+    case FLIP_F_PHI_OBJECT: p = c->phi_obj; es = 4; break;
+    case FLIP_F_VEL_U: case FLIP_F_VEL_V: case FLIP_F_VEL_W: p = c->vel[0][field - FLIP_F_VEL_U]; es = 8; break;
+    case FLIP_F_PREV_U: case FLIP_F_PREV_V: case FLIP_F_PREV_W: p = c->vel[2][field - FLIP_F_PREV_U]; es = 8; break;
+    case FLIP_F_DIFF_U: case FLIP_F_DIFF_V: case FLIP_F_DIFF_W: p = c->vel[3][field - FLIP_F_DIFF_U]; es = 8; break;
+    case FLIP_F_DISP_X: case FLIP_F_DISP_Y: case FLIP_F_DISP_Z: p = c->disp[field - FLIP_F_DISP_X]; es = 8; break;
+    case FLIP_F_WEIGHT_U: case FLIP_F_WEIGHT_V: case FLIP_F_WEIGHT_W: p = c->wgt[field - FLIP_F_WEIGHT_U]; es = 4; break;
+    case FLIP_F_FLUID_WEIGHT_U: case FLIP_F_FLUID_WEIGHT_V: case FLIP_F_FLUID_WEIGHT_W:
+        p = c->fwgt[field - FLIP_F_FLUID_WEIGHT_U]; es = 4; break;
+    case FLIP_F_OBJ_WEIGHT_U: case FLIP_F_OBJ_WEIGHT_V: case FLIP_F_OBJ_WEIGHT_W:
+        p = c->owgt[field - FLIP_F_OBJ_WEIGHT_U]; es = 4; break;
+    case FLIP_F_DENSITY: p = c->density; es = 4; break;
+    case FLIP_F_PRESSURE: p = c->x; es = 8; break;
+    case FLIP_F_VALID_U: case FLIP_F_VALID_V: case FLIP_F_VALID_W: p = c->valid[0][field - FLIP_F_VALID_U]; es = 1; break;
+    case FLIP_F_ACTIVE: p = c->active; es = 1; break;
+    case FLIP_F_LABEL: p = c->label; es = 1; break;
+    case FLIP_F_ROW_INDEX: p = c->row_index; es = 4; break;
+    case FLIP_F_BAND: p = c->band; es = 1; break;
+    default: return 1;
+    }
+    *ptr = p;
+    *elem = es;
+    return 0;
+}
+
+extern "C" int64_t flip_field_bytes(const flip_ctx *ctx, int field) {
+    void *p; int es;
+    if (!ctx || field_ptr(const_cast<flip_ctx *>(ctx), field, &p, &es)) return -1;
+    return ctx->B * es;
+}
+extern "C" int flip_field_upload(flip_ctx *ctx, int field, const void *host) {
+    FLIP_REQUIRE(ctx && host, "flip_field_upload: null argument");
+    void *p; int es;
+    FLIP_REQUIRE(field_ptr(ctx, field, &p, &es) == 0, "flip_field_upload: unknown field");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    FLIP_CHECK(hipMemcpyAsync(p, host, (size_t)ctx->B * es, hipMemcpyHostToDevice, ctx->stream));
+    FLIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int flip_field_download(flip_ctx *ctx, int field, void *host) {
+    FLIP_REQUIRE(ctx && host, "flip_field_download: null argument");
+    void *p; int es;
+    FLIP_REQUIRE(field_ptr(ctx, field, &p, &es) == 0, "flip_field_download: unknown field");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    FLIP_CHECK(hipMemcpyAsync(host, p, (size_t)ctx->B * es, hipMemcpyDeviceToHost, ctx->stream));
+    FLIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// particles
+
+__global__ void k_unpack_particles(long long n, const double *__restrict__ aos_pos, const double *__restrict__ aos_vel,
+                                   double *x, double *y, double *z, double *vx, double *vy, double *vz, int32_t *pid) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    x[i] = aos_pos[3 * i]; y[i] = aos_pos[3 * i + 1]; z[i] = aos_pos[3 * i + 2];
+    vx[i] = aos_vel[3 * i]; vy[i] = aos_vel[3 * i + 1]; vz[i] = aos_vel[3 * i + 2];
+    pid[i] = (int32_t)i;
+}
+// out[pid[s]] = (a,b,c)[s] : back to upload order
+__global__ void k_pack_particles(long long n, const double *__restrict__ a, const double *__restrict__ b,
+                                 const double *__restrict__ c, const int32_t *__restrict__ pid, double *aos) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const long long i = pid[s];
+    aos[3 * i] = a[s]; aos[3 * i + 1] = b[s]; aos[3 * i + 2] = c[s];
+}
+
+static int ensure_particle_capacity(flip_ctx *ctx, int64_t n) {
+    if (n <= ctx->cap) return 0;
+    free_particles(ctx);
+    const int64_t cap = n + n / 8 + 1024;
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        for (int a = 0; a < 6 && e == hipSuccess; ++a) e = dalloc(&ctx->p[b][a], cap);
+        if (e == hipSuccess) e = dalloc(&ctx->mass[b], cap);
+        if (e == hipSuccess) e = dalloc(&ctx->pid[b], cap);
+    }
+    if (e == hipSuccess) e = dalloc(&ctx->cell_id, cap);
+    if (e == hipSuccess) e = dalloc(&ctx->slot_src, cap);
+    if (e == hipSuccess) e = dalloc(&ctx->slot_key, cap);
+    if (e == hipSuccess) e = dalloc(&ctx->stage, cap * 6);
+    if (e != hipSuccess) return flip_fail_hip(ctx, e, "hipMalloc of the particle arrays", __FILE__, __LINE__);
+    ctx->cap = cap;
+    return 0;
+}
+
+extern "C" int flip_particles_upload(flip_ctx *ctx, int64_t n, const double *pos, const double *vel, const float *mass) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(n >= 0 && n < (int64_t)2000000000, "flip_particles_upload: particle count out of range");
+    FLIP_REQUIRE(n == 0 || (pos && vel && mass), "flip_particles_upload: null array");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    if (int rc = ensure_particle_capacity(ctx, n)) return rc;
+    ctx->n = n;
+    ctx->cur = 0;
+    ctx->binned = false;
+    if (n == 0) return 0;
+    FLIP_CHECK(hipMemcpyAsync(ctx->stage, pos, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    FLIP_CHECK(hipMemcpyAsync(ctx->stage + 3 * ctx->cap, vel, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    FLIP_CHECK(hipMemcpyAsync(ctx->mass[0], mass, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    double **q = ctx->p[0];
+    k_unpack_particles<<<flip_grid_blocks(n), FLIP_BLOCK, 0, ctx->stream>>>(
+        n, ctx->stage, ctx->stage + 3 * ctx->cap, q[0], q[1], q[2], q[3], q[4], q[5], ctx->pid[0]);
+    FLIP_LAUNCH_CHECK();
+    FLIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int flip_particles_download(flip_ctx *ctx, double *pos, double *vel) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    if (n == 0) return 0;
+    double **q = ctx->p[ctx->cur];
+    const int32_t *pid = ctx->pid[ctx->cur];
+    if (pos) {
+        k_pack_particles<<<flip_grid_blocks(n), FLIP_BLOCK, 0, ctx->stream>>>(n, q[0], q[1], q[2], pid, ctx->stage);
+        FLIP_LAUNCH_CHECK();
+        FLIP_CHECK(hipMemcpyAsync(pos, ctx->stage, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (vel) {
+        k_pack_particles<<<flip_grid_blocks(n), FLIP_BLOCK, 0, ctx->stream>>>(n, q[3], q[4], q[5], pid,
+                                                                            ctx->stage + 3 * ctx->cap);
+        FLIP_LAUNCH_CHECK();
+        FLIP_CHECK(hipMemcpyAsync(vel, ctx->stage + 3 * ctx->cap, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FLIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int64_t flip_particles_count(const flip_ctx *ctx) { return ctx ? ctx->n : -1; }
+
+// ---------------------------------------------------------------------------------------------
+// Exclusive scan of int32, three kernels: per-block scan of 2048 items, scan of the block sums
+// (recursively), uniform add.  Deterministic (integers).
+
+#define SCAN_ITEMS 8
+#define SCAN_TILE (FLIP_BLOCK * SCAN_ITEMS)
+
+__global__ void k_scan_tile(int32_t *data, long long n, int32_t *block_sums) {
+    __shared__ int32_t wave_tot[4];
+    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    int32_t v[SCAN_ITEMS];
+    int32_t s = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; ++q) {
+        v[q] = (base + q < n) ? data[base + q] : 0;
+        s += v[q];
+    }
+    // inclusive scan of s across the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t t = __shfl_up(incl, off, FLIP_WAVE);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int32_t wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+    int32_t run = wave_off + incl - s;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; ++q) {
+        if (base + q < n) data[base + q] = run;
+        run += v[q];
+    }
+    if (threadIdx.x == FLIP_BLOCK - 1 && block_sums) block_sums[blockIdx.x] = run;
+}
+__global__ void k_scan_add(int32_t *data, long long n, const int32_t *block_offsets) {
+    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    const int32_t off = block_offsets[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; ++q)
+        if (base + q < n) data[base + q] += off;
+}
+
+static int scan_rec(flip_ctx *ctx, int32_t *data, int64_t n, int32_t *tmp, int64_t tmp_len) {
+    const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb <= 1) {
+        k_scan_tile<<<1, FLIP_BLOCK, 0, ctx->stream>>>(data, n, nullptr);
+        FLIP_LAUNCH_CHECK();
+        return 0;
+    }
+    FLIP_REQUIRE(nb <= tmp_len, "scan scratch too small");
+    k_scan_tile<<<(int)nb, FLIP_BLOCK, 0, ctx->stream>>>(data, n, tmp);
+    FLIP_LAUNCH_CHECK();
+    if (int rc = scan_rec(ctx, tmp, nb, tmp + nb, tmp_len - nb)) return rc;
+    k_scan_add<<<(int)nb, FLIP_BLOCK, 0, ctx->stream>>>(data, n, tmp);
+    FLIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int flip_exclusive_scan(flip_ctx *ctx, int32_t *data, int64_t n) {
+    // scratch for all recursion levels: nb + nb/2048 + ... < nb + nb/1024 + 4
+    const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const int64_t need = nb + nb / 1024 + 8;
+    if (need > ctx->scan_tmp_len) {
+        dfree(ctx->scan_tmp);
+        hipError_t e = dalloc(&ctx->scan_tmp, need);
+        if (e != hipSuccess) return flip_fail_hip(ctx, e, "hipMalloc of the scan scratch", __FILE__, __LINE__);
+        ctx->scan_tmp_len = need;
+    }
+    return scan_rec(ctx, data, n, ctx->scan_tmp, ctx->scan_tmp_len);
+}

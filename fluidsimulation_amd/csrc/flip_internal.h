@@ -1,0 +1,192 @@
+// flip_internal.h -- shared declarations of the libflip_hip.so translation units.
+// gfx950 only: wave size 64 is hard-coded.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/flip_hip.h"
+
+#define FLIP_BLOCK 256          // threads per workgroup = cells per chunk
+#define FLIP_WAVE 64
+#define FLIP_MAX_PCG_BLOCKS 2048 // upper bound of the persistent PCG grid (partials per reduction)
+
+// Per-cell flag byte of the assembled system.
+#define FLIP_FLAG_ROW 0x40u      // the cell has a row
+// bits 0..5: the off-diagonal toward face f (-x,+x,-y,+y,-z,+z) is present
+
+struct flip_pcg_scalars {
+    double rz[2];        // r.z of the current / previous iteration (ping-pong by iteration parity)
+    double rr;           // |r|^2 of the last update
+    double rhs_norm2;    // |b|^2
+    double threshold;    // tol^2 |b|^2
+    double tol2;         // tol^2
+    double jp[6];        // J p of the current iteration (rigid-body coupling)
+    int32_t it_a;        // iteration the next direction kernel runs
+    int32_t it_b;        // iteration the next update kernel runs
+    int32_t done;        // set once converged (or |b| = 0)
+    int32_t max_iter;
+};
+
+struct flip_ctx {
+    flip_grid_desc g;
+    int64_t B = 0;       // cells in the box
+    int32_t n_chunks = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- particles, kept in cell-sorted order; pid = upload index ----
+    int64_t n = 0, cap = 0;
+    double *p[2][6] = {};   // [buffer][x y z vx vy vz]
+    float *mass[2] = {};
+    int32_t *pid[2] = {};
+    int cur = 0;            // buffer holding the current order
+    int32_t *cell_id = nullptr;     // [cap] cell of each particle in current order (B = outside)
+    int32_t *slot_src = nullptr;    // [cap] scatter scratch
+    int32_t *slot_key = nullptr;    // [cap]
+    int32_t *cell_start = nullptr;  // [B+2] exclusive scan of the per-cell counts (+1 bin for outside)
+    int32_t *cell_fill = nullptr;   // [B+1]
+    int32_t *scan_tmp = nullptr;    // block sums of the scan
+    int64_t scan_tmp_len = 0;
+    double *stage = nullptr;        // [cap*3] upload/download staging (AoS)
+    bool binned = false;
+    int64_t n_outside = 0;
+
+    // ---- dense fields ----
+    float *phi_fluid = nullptr, *phi_solid = nullptr, *phi_obj = nullptr;
+    double *vel[4][3] = {};         // 0 front, 1 back, 2 prev, 3 diff
+    double *disp[3] = {};
+    float *wgt[3] = {}, *fwgt[3] = {}, *owgt[3] = {};
+    float *density = nullptr;
+    uint8_t *valid[2][3] = {};      // front / back
+    uint8_t *active = nullptr, *active_back = nullptr;
+    uint8_t *label = nullptr, *band = nullptr, *seed = nullptr, *tmp_u8 = nullptr;
+    int32_t *row_index = nullptr;
+
+    // ---- rigid body ----
+    bool has_obj = false;
+    float phi_obj_bg = 0.f;
+    double obj_com[3] = {}, obj_minv[6] = {}, obj_vel[6] = {};
+
+    // ---- assembled system + PCG ----
+    int sys_kind = -1;
+    float sys_dt = 0.f;
+    double sys_s2 = 1.0;            // dx^2 scaling of the divergence system
+    bool sys_coupled = false;
+    bool drop_null_rows = true;     // rhs of all-zero rows forced to 0
+    float *term[3] = {};            // (1 - W) * scale at the low x/y/z face of every cell
+    uint8_t *flags = nullptr;
+    double *diag = nullptr, *invdiag = nullptr, *rhs = nullptr;
+    double *J[6] = {};              // rigid-body rows, dense over the box
+    double *x = nullptr, *r = nullptr, *z = nullptr, *pv[2] = {}, *ap = nullptr;
+    int32_t *chunk_flag = nullptr, *chunk_list = nullptr;   // [n_chunks+1]
+    int32_t *d_counts = nullptr;    // [8] device counters: 0 rows, 1 active chunks, 2 overdense, 3 outside
+    int32_t n_rows = 0, n_active_chunks = 0;
+    int pcg_blocks = 1024;
+    double *partial = nullptr;      // [16][FLIP_MAX_PCG_BLOCKS]
+    flip_pcg_scalars *scal = nullptr;
+    double *d_vmax = nullptr;       // [3*FLIP_MAX_PCG_BLOCKS]
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+};
+
+int flip_fail(flip_ctx *ctx, const char *what, const char *file, int line);
+int flip_fail_hip(flip_ctx *ctx, hipError_t e, const char *what, const char *file, int line);
+
+#define FLIP_CHECK(call)                                                        \
+    do {                                                                        \
+        hipError_t e_ = (call);                                                 \
+        if (e_ != hipSuccess) return flip_fail_hip(ctx, e_, #call, __FILE__, __LINE__); \
+    } while (0)
+#define FLIP_REQUIRE(cond, msg)                                                 \
+    do {                                                                        \
+        if (!(cond)) return flip_fail(ctx, msg, __FILE__, __LINE__);            \
+    } while (0)
+#define FLIP_LAUNCH_CHECK() FLIP_CHECK(hipGetLastError())
+
+static inline int flip_grid_blocks(int64_t n) { return (int)((n + FLIP_BLOCK - 1) / FLIP_BLOCK); }
+
+// Exclusive scan of int32 data[0..n) in place (device); total written to *total_out (device) if not null.
+int flip_exclusive_scan(flip_ctx *ctx, int32_t *data, int64_t n);
+
+// ---------------------------------------------------------------------------------------------
+// Device helpers.  Arithmetic types mirror the reference expression by expression.
+
+struct GridDims {
+    int nx, ny, nz, ox, oy, oz;
+    long long B;
+};
+static inline GridDims flip_dims(const flip_ctx *c) {
+    return GridDims{ c->g.nx, c->g.ny, c->g.nz, c->g.ox, c->g.oy, c->g.oz, (long long)c->B };
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ bool d_inside(const GridDims &g, int i, int j, int k) {
+    return i >= 0 && j >= 0 && k >= 0 && i < g.nx && j < g.ny && k < g.nz;
+}
+__device__ __forceinline__ long long d_lid(const GridDims &g, int i, int j, int k) {
+    return (long long)i + (long long)g.nx * ((long long)j + (long long)g.ny * k);
+}
+__device__ __forceinline__ void d_ijk(const GridDims &g, long long c, int &i, int &j, int &k) {
+    i = (int)(c % g.nx);
+    long long t = c / g.nx;
+    j = (int)(t % g.ny);
+    k = (int)(t / g.ny);
+}
+__device__ __forceinline__ float d_getf(const GridDims &g, const float *a, int i, int j, int k, float bg) {
+    return d_inside(g, i, j, k) ? a[d_lid(g, i, j, k)] : bg;
+}
+__device__ __forceinline__ double d_getd(const GridDims &g, const double *a, int i, int j, int k) {
+    return d_inside(g, i, j, k) ? a[d_lid(g, i, j, k)] : 0.0;
+}
+
+// headers/util.h:470-478 (T = double)
+__device__ __forceinline__ double d_hat(double x) {
+    if (-1. <= x && x <= 0.) return 1 + x;
+    else if (0. <= x && x <= 1.) return 1 - x;
+    else return 0;
+}
+// headers/util.h:200-208
+__device__ __forceinline__ float d_clampf(float a, float lo, float hi) { return a < lo ? lo : (a > hi ? hi : a); }
+// headers/util.h:493-501 (T = float)
+__device__ __forceinline__ float d_frac2(float l, float r) {
+    if (l < 0 && r < 0) return 1;
+    if (l < 0 && r >= 0) return l / (l - r);
+    if (l >= 0 && r < 0) return r / (r - l);
+    return 0;
+}
+// max(0.001f, fraction_inside(a, b)) as used for the ghost-fluid theta
+__device__ __forceinline__ float d_theta(float l, float r) {
+    const float t = d_frac2(l, r);
+    return 0.001f > t ? 0.001f : t;
+}
+// headers/util.h:505-580 (T = float)
+__device__ float d_frac4(float phi_bl, float phi_br, float phi_tl, float phi_tr);
+
+// Sum over the 256 threads of a workgroup in a fixed order (lane tree, then waves 0..3);
+// every thread receives the result.  scratch: 4 doubles of LDS.
+__device__ __forceinline__ double d_block_sum(double v, double *scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, FLIP_WAVE);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    return ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+}
+__device__ __forceinline__ double d_block_max(double v, double *scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, FLIP_WAVE));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    return fmax(fmax(scratch[0], scratch[1]), fmax(scratch[2], scratch[3]));
+}
+#endif

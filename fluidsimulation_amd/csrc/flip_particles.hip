@@ -1,0 +1,426 @@
+// flip_particles.hip -- particle-side kernels: counting-sort binning, occupancy bands, P2G gather,
+// G2P, displacement sampling and the density field.
+#include "flip_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// Binning.  cell(p) = floor(pos + 0.5) per axis (OpenVDB Coord::round of the index position).
+// Outside particles go to the extra bin B.
+
+__global__ void k_cell_ids(GridDims g, long long n, const double *__restrict__ x, const double *__restrict__ y,
+                           const double *__restrict__ z, int32_t *__restrict__ cell_id, int32_t *__restrict__ counts) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int i = (int)floor(x[s] + 0.5) - g.ox;
+    const int j = (int)floor(y[s] + 0.5) - g.oy;
+    const int k = (int)floor(z[s] + 0.5) - g.oz;
+    const int32_t c = d_inside(g, i, j, k) ? (int32_t)d_lid(g, i, j, k) : (int32_t)g.B;
+    cell_id[s] = c;
+    atomicAdd(&counts[c], 1); // integer: the result does not depend on the order of arrival
+}
+
+__global__ void k_scatter_slots(long long n, const int32_t *__restrict__ cell_id, const int32_t *__restrict__ pid,
+                                const int32_t *__restrict__ cell_start, int32_t *__restrict__ fill,
+                                int32_t *__restrict__ slot_src, int32_t *__restrict__ slot_key) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int32_t c = cell_id[s];
+    const int32_t slot = cell_start[c] + atomicAdd(&fill[c], 1);
+    slot_src[slot] = (int32_t)s;
+    slot_key[slot] = pid[s];
+}
+
+// max-heap sift of (key, src) pairs within [0, lim)
+__device__ void d_sift_down(int32_t *key, int32_t *src, int32_t root, int32_t lim) {
+    const int32_t rk = key[root], rs = src[root];
+    int32_t hole = root;
+    for (;;) {
+        int32_t child = 2 * hole + 1;
+        if (child >= lim) break;
+        if (child + 1 < lim && key[child + 1] > key[child]) ++child;
+        if (key[child] <= rk) break;
+        key[hole] = key[child];
+        src[hole] = src[child];
+        hole = child;
+    }
+    key[hole] = rk;
+    src[hole] = rs;
+}
+
+// The atomic ranks above depend on timing; sorting each cell's slots by upload index makes the final
+// order the stable one.  One thread per cell: insertion sort (cells hold a handful of particles),
+// heapsort for a crowded cell.  The bin of the outside particles is left unsorted (the host passes
+// n_bins = B): its order affects nothing, and it may be large.
+__global__ void k_sort_cells(long long n_bins, const int32_t *__restrict__ cell_start, int32_t *__restrict__ slot_src,
+                             int32_t *__restrict__ slot_key) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_bins) return;
+    const int32_t b = cell_start[c], e = cell_start[c + 1];
+    const int32_t m = e - b;
+    if (m < 2) return;
+    if (m > 48) {
+        // crowded cell: in-place heapsort keeps the work at m log m for one thread
+        int32_t *key = slot_key + b, *src = slot_src + b;
+        for (int32_t root = m / 2 - 1; root >= 0; --root) d_sift_down(key, src, root, m);
+        for (int32_t end = m - 1; end > 0; --end) {
+            const int32_t tk = key[0], ts = src[0];
+            key[0] = key[end]; src[0] = src[end];
+            key[end] = tk; src[end] = ts;
+            d_sift_down(key, src, 0, end);
+        }
+        return;
+    }
+    for (int32_t a = b + 1; a < e; ++a) {
+        const int32_t key = slot_key[a], src = slot_src[a];
+        int32_t q = a - 1;
+        while (q >= b && slot_key[q] > key) {
+            slot_key[q + 1] = slot_key[q];
+            slot_src[q + 1] = slot_src[q];
+            --q;
+        }
+        slot_key[q + 1] = key;
+        slot_src[q + 1] = src;
+    }
+}
+
+struct ParticlePtrs {
+    double *a[6];
+    float *mass;
+    int32_t *pid;
+};
+__global__ void k_reorder(long long n, const int32_t *__restrict__ slot_src, const int32_t *__restrict__ slot_key,
+                          const int32_t *__restrict__ cell_id_old, ParticlePtrs src, ParticlePtrs dst) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int32_t o = slot_src[s];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dst.a[q][s] = src.a[q][o];
+    dst.mass[s] = src.mass[o];
+    dst.pid[s] = slot_key[s];
+    (void)cell_id_old;
+}
+
+// Occupancy bands: bit0 = within 1 cell of a particle cell, bit1 = within 2 (Chebyshev distance).
+// Box dilation is separable: one pass per axis.
+__global__ void k_band_x(GridDims g, const int32_t *__restrict__ cell_start, uint8_t *__restrict__ out) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.B) return;
+    int i, j, k;
+    d_ijk(g, c, i, j, k);
+    uint8_t m = 0;
+    for (int d = -2; d <= 2; ++d) {
+        const int ii = i + d;
+        if (ii < 0 || ii >= g.nx) continue;
+        const long long n = c + d;
+        if (cell_start[n + 1] > cell_start[n]) m |= (d >= -1 && d <= 1) ? 3 : 2;
+    }
+    out[c] = m;
+}
+__global__ void k_band_axis(GridDims g, int axis, const uint8_t *__restrict__ in, uint8_t *__restrict__ out) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.B) return;
+    int i, j, k;
+    d_ijk(g, c, i, j, k);
+    const int pos = axis == 1 ? j : k, lim = axis == 1 ? g.ny : g.nz;
+    const long long stride = axis == 1 ? g.nx : (long long)g.nx * g.ny;
+    uint8_t m = 0;
+    for (int d = -2; d <= 2; ++d) {
+        if (pos + d < 0 || pos + d >= lim) continue;
+        const uint8_t v = in[c + d * stride];
+        if (d >= -1 && d <= 1) m |= v;
+        else m |= (v & 2);
+    }
+    // bit0 needs distance <= 1 on every axis, bit1 distance <= 2: bit0 of a +-2 neighbour does not
+    // count, and bit1 of any neighbour within 2 does
+    out[c] = m;
+}
+
+extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    const GridDims g = flip_dims(ctx);
+    const int64_t n = ctx->n, B = ctx->B;
+    hipStream_t st = ctx->stream;
+    FLIP_CHECK(hipMemsetAsync(ctx->cell_start, 0, (size_t)(B + 2) * 4, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->cell_fill, 0, (size_t)(B + 1) * 4, st));
+    const int src = ctx->cur, dst = 1 - src;
+    if (n > 0) {
+        k_cell_ids<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(g, n, ctx->p[src][0], ctx->p[src][1], ctx->p[src][2],
+                                                              ctx->cell_id, ctx->cell_start);
+        FLIP_LAUNCH_CHECK();
+    }
+    if (int rc = flip_exclusive_scan(ctx, ctx->cell_start, B + 2)) return rc;
+    if (n > 0) {
+        k_scatter_slots<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->cell_id, ctx->pid[src], ctx->cell_start,
+                                                                   ctx->cell_fill, ctx->slot_src, ctx->slot_key);
+        FLIP_LAUNCH_CHECK();
+        k_sort_cells<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(B, ctx->cell_start, ctx->slot_src, ctx->slot_key);
+        FLIP_LAUNCH_CHECK();
+        ParticlePtrs ps, pd;
+        for (int q = 0; q < 6; ++q) { ps.a[q] = ctx->p[src][q]; pd.a[q] = ctx->p[dst][q]; }
+        ps.mass = ctx->mass[src]; pd.mass = ctx->mass[dst];
+        ps.pid = ctx->pid[src]; pd.pid = ctx->pid[dst];
+        k_reorder<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->slot_src, ctx->slot_key, ctx->cell_id, ps, pd);
+        FLIP_LAUNCH_CHECK();
+        ctx->cur = dst;
+    }
+    k_band_x<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, ctx->cell_start, ctx->band);
+    FLIP_LAUNCH_CHECK();
+    k_band_axis<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, 1, ctx->band, ctx->tmp_u8);
+    FLIP_LAUNCH_CHECK();
+    k_band_axis<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, 2, ctx->tmp_u8, ctx->band);
+    FLIP_LAUNCH_CHECK();
+    ctx->binned = true;
+    if (n_outside) {
+        int32_t ends[2];
+        FLIP_CHECK(hipMemcpyAsync(ends, ctx->cell_start + B, 8, hipMemcpyDeviceToHost, st));
+        FLIP_CHECK(hipStreamSynchronize(st));
+        ctx->n_outside = (int64_t)ends[1] - ends[0];
+        *n_outside = ctx->n_outside;
+    }
+    return 0;
+}
+
+__global__ void k_cell_id_by_pid(long long n, long long B, const int32_t *__restrict__ cell_start_unused,
+                                 const int32_t *__restrict__ pid, const double *__restrict__ x,
+                                 const double *__restrict__ y, const double *__restrict__ z, GridDims g,
+                                 int32_t *__restrict__ out) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int i = (int)floor(x[s] + 0.5) - g.ox;
+    const int j = (int)floor(y[s] + 0.5) - g.oy;
+    const int k = (int)floor(z[s] + 0.5) - g.oz;
+    out[pid[s]] = d_inside(g, i, j, k) ? (int32_t)d_lid(g, i, j, k) : -1;
+    (void)B; (void)cell_start_unused;
+}
+
+extern "C" int flip_binning_download(flip_ctx *ctx, int32_t *cell_id, int32_t *cell_start, int32_t *perm) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(ctx->binned, "flip_binning_download: call flip_bin_particles first");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t n = ctx->n;
+    if (cell_id && n > 0) {
+        k_cell_id_by_pid<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->B, nullptr, ctx->pid[ctx->cur],
+                                                                    ctx->p[ctx->cur][0], ctx->p[ctx->cur][1],
+                                                                    ctx->p[ctx->cur][2], flip_dims(ctx), ctx->slot_src);
+        FLIP_LAUNCH_CHECK();
+        FLIP_CHECK(hipMemcpyAsync(cell_id, ctx->slot_src, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (cell_start) FLIP_CHECK(hipMemcpyAsync(cell_start, ctx->cell_start, (size_t)(ctx->B + 1) * 4, hipMemcpyDeviceToHost, st));
+    if (perm && n > 0) FLIP_CHECK(hipMemcpyAsync(perm, ctx->pid[ctx->cur], (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    FLIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// P2G gather (src/FluidSimulator.cpp:71-118, src/Functors.cpp:10-45, kernel :1361-1371).
+// One thread per cell of the band.  The particles of the three x-neighbours of a grid row are
+// contiguous in the sorted arrays, so each (dy,dz) row is one slot range.  Accumulation order:
+// ascending neighbour cell id, sorted slots within a cell.
+
+__global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const uint8_t *__restrict__ band,
+                      const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+                      const double *__restrict__ vx, const double *__restrict__ vy, const double *__restrict__ vz,
+                      double *__restrict__ u, double *__restrict__ v, double *__restrict__ w, uint8_t *__restrict__ active) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.B) return;
+    if (!(band[c] & 2)) {
+        u[c] = 0.0; v[c] = 0.0; w[c] = 0.0;
+        active[c] = 0;
+        return;
+    }
+    int i, j, k;
+    d_ijk(g, c, i, j, k);
+    const double eps = (double)10e-37f; // background of the weight grid (src/FluidSimulator.cpp:32,77)
+    double ws0 = eps, ws1 = eps, ws2 = eps, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const double cx = (double)(g.ox + i), cy = (double)(g.oy + j), cz = (double)(g.oz + k);
+    const int i0 = i > 0 ? i - 1 : 0, i1 = i < g.nx - 1 ? i + 1 : g.nx - 1;
+    for (int kk = k - 1; kk <= k + 1; ++kk) {
+        if (kk < 0 || kk >= g.nz) continue;
+        for (int jj = j - 1; jj <= j + 1; ++jj) {
+            if (jj < 0 || jj >= g.ny) continue;
+            const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
+            const int32_t s0 = cell_start[row + i0], s1 = cell_start[row + i1 + 1];
+            for (int32_t s = s0; s < s1; ++s) {
+                const double d0 = px[s] - cx, d1 = py[s] - cy, d2 = pz[s] - cz;
+                if (d0 < -1. || d0 > 1. || d1 < -1. || d1 > 1. || d2 < -1. || d2 > 1.) continue;
+                const float x0 = (float)d_hat(d0), y0 = (float)d_hat(d1), z0 = (float)d_hat(d2);
+                const float x1 = (float)d_hat(d0 + 0.5), y1 = (float)d_hat(d1 + 0.5), z1 = (float)d_hat(d2 + 0.5);
+                const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
+                if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
+                    ws0 = ws0 + w0; ws1 = ws1 + w1; ws2 = ws2 + w2;
+                    a0 = a0 + w0 * vx[s]; a1 = a1 + w1 * vy[s]; a2 = a2 + w2 * vz[s];
+                }
+            }
+        }
+    }
+    u[c] = a0 / ws0;
+    v[c] = a1 / ws1;
+    w[c] = a2 / ws2;
+    active[c] = 1;
+}
+
+extern "C" int flip_p2g(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(ctx->binned, "flip_p2g: call flip_bin_particles first");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    double **q = ctx->p[ctx->cur];
+    // the gather writes the back buffer, then the buffers swap (src/FluidSimulator.cpp:74,117)
+    k_p2g<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->cell_start, ctx->band, q[0], q[1],
+                                                                   q[2], q[3], q[4], q[5], ctx->vel[1][0], ctx->vel[1][1],
+                                                                   ctx->vel[1][2], ctx->active);
+    FLIP_LAUNCH_CHECK();
+    for (int a = 0; a < 3; ++a) std::swap(ctx->vel[0][a], ctx->vel[1][a]);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Staggered trilinear sampling (OpenVDB StaggeredBoxSampler as used by MacGrid::StaggeredSampler,
+// headers/MacGrid.h:36-37): component c at pos + e_c/2; z, then y, then x; each step a + (b-a)*t.
+
+__device__ __forceinline__ double d_lerp(double a, double b, double t) {
+    const double tmp = (b - a) * t;
+    return a + tmp;
+}
+__device__ __forceinline__ double d_box_sample(const GridDims &g, const double *__restrict__ f, double x, double y, double z) {
+    const double fx = floor(x), fy = floor(y), fz = floor(z);
+    const int i = (int)fx - g.ox, j = (int)fy - g.oy, k = (int)fz - g.oz;
+    const double tu = x - fx, tv = y - fy, tw = z - fz;
+    double d000, d001, d010, d011, d100, d101, d110, d111;
+    if (i >= 0 && j >= 0 && k >= 0 && i + 1 < g.nx && j + 1 < g.ny && k + 1 < g.nz) {
+        const long long c = d_lid(g, i, j, k), sy = g.nx, sz = (long long)g.nx * g.ny;
+        d000 = f[c]; d100 = f[c + 1];
+        d010 = f[c + sy]; d110 = f[c + sy + 1];
+        d001 = f[c + sz]; d101 = f[c + sz + 1];
+        d011 = f[c + sz + sy]; d111 = f[c + sz + sy + 1];
+    } else {
+        d000 = d_getd(g, f, i, j, k); d100 = d_getd(g, f, i + 1, j, k);
+        d010 = d_getd(g, f, i, j + 1, k); d110 = d_getd(g, f, i + 1, j + 1, k);
+        d001 = d_getd(g, f, i, j, k + 1); d101 = d_getd(g, f, i + 1, j, k + 1);
+        d011 = d_getd(g, f, i, j + 1, k + 1); d111 = d_getd(g, f, i + 1, j + 1, k + 1);
+    }
+    return d_lerp(d_lerp(d_lerp(d000, d001, tw), d_lerp(d010, d011, tw), tv),
+                  d_lerp(d_lerp(d100, d101, tw), d_lerp(d110, d111, tw), tv), tu);
+}
+
+__global__ void k_g2p(GridDims g, long long n, const double *__restrict__ px, const double *__restrict__ py,
+                      const double *__restrict__ pz, double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
+                      const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
+                      const double *__restrict__ du, const double *__restrict__ dv, const double *__restrict__ dw,
+                      float ratio) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const double x = px[s], y = py[s], z = pz[s];
+    const float one_minus = 1 - ratio; // float expression in the reference (src/FluidSimulator.cpp:132)
+    const double pic0 = d_box_sample(g, u, x + 0.5, y, z);
+    const double pic1 = d_box_sample(g, v, x, y + 0.5, z);
+    const double pic2 = d_box_sample(g, w, x, y, z + 0.5);
+    const double dif0 = d_box_sample(g, du, x + 0.5, y, z);
+    const double dif1 = d_box_sample(g, dv, x, y + 0.5, z);
+    const double dif2 = d_box_sample(g, dw, x, y, z + 0.5);
+    const double f0 = vx[s] + dif0, f1 = vy[s] + dif1, f2 = vz[s] + dif2;
+    vx[s] = pic0 * (double)one_minus + f0 * (double)ratio;
+    vy[s] = pic1 * (double)one_minus + f1 * (double)ratio;
+    vz[s] = pic2 * (double)one_minus + f2 * (double)ratio;
+}
+
+extern "C" int flip_g2p(flip_ctx *ctx, float ratio) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->n == 0) return 0;
+    double **q = ctx->p[ctx->cur];
+    k_g2p<<<flip_grid_blocks(ctx->n), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->n, q[0], q[1], q[2], q[3], q[4], q[5],
+                                                                   ctx->vel[0][0], ctx->vel[0][1], ctx->vel[0][2],
+                                                                   ctx->vel[3][0], ctx->vel[3][1], ctx->vel[3][2], ratio);
+    FLIP_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void k_apply_disp(GridDims g, long long n, double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
+                             const double *__restrict__ dx, const double *__restrict__ dy, const double *__restrict__ dz) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const double x = px[s], y = py[s], z = pz[s];
+    const double e0 = d_box_sample(g, dx, x + 0.5, y, z);
+    const double e1 = d_box_sample(g, dy, x, y + 0.5, z);
+    const double e2 = d_box_sample(g, dz, x, y, z + 0.5);
+    px[s] = x + e0;
+    py[s] = y + e1;
+    pz[s] = z + e2;
+}
+
+extern "C" int flip_apply_displacements(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->n == 0) return 0;
+    double **q = ctx->p[ctx->cur];
+    k_apply_disp<<<flip_grid_blocks(ctx->n), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->n, q[0], q[1], q[2], ctx->disp[0],
+                                                                          ctx->disp[1], ctx->disp[2]);
+    FLIP_LAUNCH_CHECK();
+    ctx->binned = false; // positions moved: the sort is stale
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Density (src/FluidSimulator.cpp:625-652, src/Functors.cpp:216-266).
+
+__global__ void k_density(GridDims g, float phi_bg, float rest, double vs3, const int32_t *__restrict__ cell_start,
+                          const uint8_t *__restrict__ band, const float *__restrict__ phi, const double *__restrict__ px,
+                          const double *__restrict__ py, const double *__restrict__ pz, const float *__restrict__ mass,
+                          float *__restrict__ density, int32_t *__restrict__ n_over) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.B) return;
+    if (!(band[c] & 2)) { density[c] = 0.f; return; }
+    int i, j, k;
+    d_ijk(g, c, i, j, k);
+    const float pc = phi[c];
+    const float fw = d_frac2(d_getf(g, phi, i - 1, j, k, phi_bg), pc) + d_frac2(d_getf(g, phi, i, j - 1, k, phi_bg), pc)
+                     + d_frac2(d_getf(g, phi, i, j, k - 1, phi_bg), pc) + d_frac2(d_getf(g, phi, i + 1, j, k, phi_bg), pc)
+                     + d_frac2(d_getf(g, phi, i, j + 1, k, phi_bg), pc) + d_frac2(d_getf(g, phi, i, j, k + 1, phi_bg), pc);
+    float dens = 0.f;
+    const double denom = (double)(fw / 6) * vs3;
+    const double cx = (double)(g.ox + i), cy = (double)(g.oy + j), cz = (double)(g.oz + k);
+    const int i0 = i > 0 ? i - 1 : 0, i1 = i < g.nx - 1 ? i + 1 : g.nx - 1;
+    if (fw > 0) {
+        for (int kk = k - 1; kk <= k + 1; ++kk) {
+            if (kk < 0 || kk >= g.nz) continue;
+            for (int jj = j - 1; jj <= j + 1; ++jj) {
+                if (jj < 0 || jj >= g.ny) continue;
+                const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
+                const int32_t s0 = cell_start[row + i0], s1 = cell_start[row + i1 + 1];
+                for (int32_t s = s0; s < s1; ++s) {
+                    const double d0 = px[s] - cx, d1 = py[s] - cy, d2 = pz[s] - cz;
+                    if (d0 < -1. || d0 > 1. || d1 < -1. || d1 > 1. || d2 < -1. || d2 > 1.) continue;
+                    const double wgt = d_hat(d0) * d_hat(d1) * d_hat(d2);
+                    if (wgt > 0) {
+                        const double add = (double)0.f + wgt * (double)mass[s] / denom;
+                        dens = (float)((double)dens + add);
+                    }
+                }
+            }
+        }
+    }
+    if (0 < fw && fw < 6) dens = dens > rest ? dens : rest;
+    density[c] = dens;
+    if ((double)dens > 1.5 * (double)rest) atomicAdd(n_over, 1);
+}
+
+extern "C" int flip_density(flip_ctx *ctx, int64_t *n_overdense) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(ctx->binned, "flip_density: call flip_bin_particles first");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    double **q = ctx->p[ctx->cur];
+    const double vs3 = pow((double)ctx->g.dx, 3);
+    FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
+    k_density<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->g.phi_fluid_bg, ctx->g.rest_density, vs3,
+                                                                       ctx->cell_start, ctx->band, ctx->phi_fluid, q[0], q[1],
+                                                                       q[2], ctx->mass[ctx->cur], ctx->density, ctx->d_counts + 2);
+    FLIP_LAUNCH_CHECK();
+    if (n_overdense) {
+        int32_t v = 0;
+        FLIP_CHECK(hipMemcpyAsync(&v, ctx->d_counts + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+        FLIP_CHECK(hipStreamSynchronize(ctx->stream));
+        *n_overdense = v;
+    }
+    return 0;
+}

@@ -1,0 +1,607 @@
+// flip_pcg.hip -- matrix-free assembly of the two pressure systems and the conjugate-gradient solver.
+//
+// The system of src/FluidSimulator.cpp:654-816 / 832-990 is never stored as a sparse matrix.  Per cell
+// the library keeps: three float face terms (1 - W) * scale at the low x/y/z faces (the high faces of
+// a cell are the low faces of its neighbours), one flag byte (row present, which of the six
+// off-diagonals exist), the diagonal and its Jacobi inverse in double, and the right-hand side.
+// Vectors are dense over the box and zero off the rows.  Work is organised in chunks of 256
+// consecutive cells; only chunks that contain a row are swept (compact list built at assembly).
+//
+// One CG iteration is two kernels:
+//   k_pcg_direction: beta from the reduced partials; p = z + beta p (evaluated on the fly at the 7
+//                    stencil points), Ap = A p, partial p.Ap
+//   k_pcg_update   : alpha; x += alpha p; r -= alpha Ap; z = Dinv r; partials r.r and r.z
+// Dot products are reduced without atomics: every workgroup writes one partial per quantity, and
+// every workgroup of the next kernel sums all partials in the same fixed order, so all workgroups
+// hold the same scalar and the result is reproducible run to run.
+#include "flip_internal.h"
+
+#include <cfloat>
+
+// ---------------------------------------------------------------------------------------------
+// Assembly
+
+struct BuildArgs {
+    GridDims g;
+    int kind;
+    float dt, rho, vs, scale, fbg, sbg;
+    double s2;
+    const uint8_t *label;
+    const float *phi_f, *phi_s, *wu, *wv, *ww, *density;
+    const double *u, *v, *w;
+    float *tx, *ty, *tz;
+    uint8_t *flags;
+    double *diag, *invdiag, *rhs;
+    int32_t *chunk_flag;
+    // rigid-body coupling (kind 0 only)
+    int coupled;
+    int drop_null;
+    const float *ou, *ov, *ow;
+    double com[3], minv[6], vel[6];
+    double *J[6];
+};
+
+__global__ void k_build_system(BuildArgs A) {
+    const GridDims &g = A.g;
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int is_row = 0;
+    if (c < g.B) {
+        int i, j, k;
+        d_ijk(g, c, i, j, k);
+        const float w_lo[3] = { A.wu[c], A.wv[c], A.ww[c] };
+        A.tx[c] = (1 - w_lo[0]) * A.scale;
+        A.ty[c] = (1 - w_lo[1]) * A.scale;
+        A.tz[c] = (1 - w_lo[2]) * A.scale;
+        uint8_t fl = 0;
+        double dg = 0.0, inv = 1.0, rh = 0.0;
+        double Jr[6] = { 0, 0, 0, 0, 0, 0 };
+        if (A.label[c]) {
+            is_row = 1;
+            fl = FLIP_FLAG_ROW;
+            const float phi_c = A.phi_f[c];
+            double diagonal = 0, r = 0;
+            float wsum = 0;
+            const int di[6] = { -1, 1, 0, 0, 0, 0 }, dj[6] = { 0, 0, -1, 1, 0, 0 }, dk[6] = { 0, 0, 0, 0, -1, 1 };
+#pragma unroll
+            for (int f = 0; f < 6; ++f) {
+                const int ni = i + di[f], nj = j + dj[f], nk = k + dk[f];
+                const bool in = d_inside(g, ni, nj, nk);
+                const long long nb = in ? d_lid(g, ni, nj, nk) : 0;
+                const float phi_n = in ? A.phi_f[nb] : A.fbg;
+                const float sphi_n = in ? A.phi_s[nb] : A.sbg;
+                const float *wa = f < 2 ? A.wu : (f < 4 ? A.wv : A.ww);
+                const float wval = (f & 1) ? (in ? wa[nb] : 0.f) : w_lo[f >> 1];
+                const float weight = 1 - wval;
+                const double term = (double)(weight * A.scale);
+                if (phi_n < 0) {
+                    // the off-diagonal multiplies a vector entry only where the neighbour has a row
+                    if (in && A.label[nb]) fl |= (uint8_t)(1u << f);
+                    diagonal += term;
+                } else if (sphi_n > 0) {
+                    const float th = (f & 1) ? d_theta(phi_c, phi_n) : d_theta(phi_n, phi_c);
+                    diagonal += term * ((double)1.f / (double)th);
+                }
+                if (A.kind == 0) {
+                    const double *va = f < 2 ? A.u : (f < 4 ? A.v : A.w);
+                    if (f & 1) r -= (double)weight * (in ? va[nb] : 0.0);
+                    else r += (double)weight * va[c];
+                } else {
+                    wsum = wsum + weight;
+                }
+            }
+            if (A.kind == 0) {
+                dg = diagonal * A.s2;
+                rh = r * A.s2;
+            } else {
+                dg = diagonal;
+                float rr = -1 / A.dt * (1 - d_clampf(A.density[c] / A.rho, 0.5f, 1.5f));
+                if (wsum == 0) rr = 0;
+                rh = (double)rr;
+            }
+            double dfull = dg;
+            if (A.coupled) { // SolidObject::constructJMatrix (src/SolidObject.cpp:159-185)
+                const float vs2 = A.vs * A.vs;
+                const float du = d_getf(g, A.ou, i + 1, j, k, 0.f) - A.ou[c];
+                const float dv = d_getf(g, A.ov, i, j + 1, k, 0.f) - A.ov[c];
+                const float dw = d_getf(g, A.ow, i, j, k + 1, 0.f) - A.ow[c];
+                const double rx = (double)(g.ox + i) - A.com[0], ry = (double)(g.oy + j) - A.com[1],
+                             rz = (double)(g.oz + k) - A.com[2];
+                Jr[0] = (double)(vs2 * du);
+                Jr[1] = (double)(vs2 * dv);
+                Jr[2] = (double)(vs2 * dw);
+                Jr[3] = (double)vs2 * ((double)(-A.vs) * rz * (double)dv + (double)A.vs * ry * (double)dw);
+                Jr[4] = (double)vs2 * ((double)(-A.vs) * rx * (double)dw + (double)A.vs * rz * (double)du);
+                Jr[5] = (double)vs2 * ((double)(-A.vs) * ry * (double)du + (double)A.vs * rx * (double)dv);
+                double s = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    s += Jr[a] * A.vel[a];                                  // rhs -= J^T V        (:815)
+                    dfull += (double)A.dt * A.minv[a] * Jr[a] * Jr[a];      // diag of dt J^T Minv J (:813)
+                }
+                rh = rh - s;
+            }
+            inv = dfull != 0 ? 1.0 / dfull : 1.0; // Eigen DiagonalPreconditioner
+            if (A.drop_null && dfull == 0) rh = 0.0; // all-zero row: nothing to solve for
+        }
+        A.flags[c] = fl;
+        A.diag[c] = dg;
+        A.invdiag[c] = inv;
+        A.rhs[c] = rh;
+        if (A.coupled)
+#pragma unroll
+            for (int a = 0; a < 6; ++a) A.J[a][c] = Jr[a];
+    }
+    const int any = __syncthreads_or(is_row);
+    if (threadIdx.x == 0) A.chunk_flag[blockIdx.x] = any ? 1 : 0;
+}
+
+__global__ void k_compact_chunks(int n_chunks, const int32_t *__restrict__ flag_scan, const int32_t *__restrict__ flag_raw_next,
+                                 int32_t *__restrict__ list) {
+    // flag_scan holds the exclusive scan of the chunk flags over n_chunks+1 entries; chunk q is active
+    // when scan[q+1] > scan[q]
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_chunks) return;
+    (void)flag_raw_next;
+    if (flag_scan[q + 1] > flag_scan[q]) list[flag_scan[q]] = q;
+}
+
+extern "C" int flip_set_null_row_policy(flip_ctx *ctx, int drop) {
+    FLIP_REQUIRE(ctx, "null context");
+    ctx->drop_null_rows = drop != 0;
+    return 0;
+}
+
+extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(kind == FLIP_SOLVE_DIVERGENCE || kind == FLIP_SOLVE_DENSITY, "flip_build_system: unknown kind");
+    FLIP_REQUIRE(dt > 0.f, "flip_build_system: dt must be positive");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    BuildArgs A;
+    memset(&A, 0, sizeof A);
+    A.g = flip_dims(ctx);
+    A.kind = kind;
+    A.dt = dt;
+    A.rho = ctx->g.rest_density;
+    A.vs = ctx->g.dx;
+    // float expressions of src/FluidSimulator.cpp:692 and :870
+    A.scale = kind == 0 ? dt / (A.rho * A.vs) : dt / (A.rho * (A.vs * A.vs));
+    A.s2 = kind == 0 ? (double)(A.vs * A.vs) : 1.0;
+    A.fbg = ctx->g.phi_fluid_bg;
+    A.sbg = ctx->g.phi_solid_bg;
+    A.label = ctx->label;
+    A.phi_f = ctx->phi_fluid; A.phi_s = ctx->phi_solid;
+    A.wu = ctx->wgt[0]; A.wv = ctx->wgt[1]; A.ww = ctx->wgt[2];
+    A.density = ctx->density;
+    A.u = ctx->vel[0][0]; A.v = ctx->vel[0][1]; A.w = ctx->vel[0][2];
+    A.tx = ctx->term[0]; A.ty = ctx->term[1]; A.tz = ctx->term[2];
+    A.flags = ctx->flags; A.diag = ctx->diag; A.invdiag = ctx->invdiag; A.rhs = ctx->rhs;
+    A.chunk_flag = ctx->chunk_flag;
+    A.coupled = (kind == 0 && ctx->has_obj) ? 1 : 0;
+    A.drop_null = ctx->drop_null_rows ? 1 : 0;
+    A.ou = ctx->owgt[0]; A.ov = ctx->owgt[1]; A.ow = ctx->owgt[2];
+    for (int a = 0; a < 3; ++a) A.com[a] = ctx->obj_com[a];
+    for (int a = 0; a < 6; ++a) { A.minv[a] = ctx->obj_minv[a]; A.vel[a] = ctx->obj_vel[a]; A.J[a] = ctx->J[a]; }
+    FLIP_CHECK(hipMemsetAsync(ctx->chunk_flag + ctx->n_chunks, 0, 4, st));
+    k_build_system<<<ctx->n_chunks, FLIP_BLOCK, 0, st>>>(A);
+    FLIP_LAUNCH_CHECK();
+    if (int rc = flip_exclusive_scan(ctx, ctx->chunk_flag, ctx->n_chunks + 1)) return rc;
+    k_compact_chunks<<<flip_grid_blocks(ctx->n_chunks), FLIP_BLOCK, 0, st>>>(ctx->n_chunks, ctx->chunk_flag, nullptr, ctx->chunk_list);
+    FLIP_LAUNCH_CHECK();
+    FLIP_CHECK(hipMemcpyAsync(ctx->d_counts + 1, ctx->chunk_flag + ctx->n_chunks, 4, hipMemcpyDeviceToDevice, st));
+    ctx->sys_kind = kind;
+    ctx->sys_dt = dt;
+    ctx->sys_s2 = A.s2;
+    ctx->sys_coupled = A.coupled != 0;
+    return 0;
+}
+
+// expands the compact representation into the 7-point stencil for the parity hook
+__global__ void k_expand_stencil(GridDims g, double s2, const uint8_t *__restrict__ flags, const float *__restrict__ tx,
+                                 const float *__restrict__ ty, const float *__restrict__ tz, double *__restrict__ off) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.B) return;
+    const uint8_t fl = flags[c];
+    const long long sy = g.nx, sz = (long long)g.nx * g.ny;
+    off[0 * g.B + c] = (fl & 1) ? -((double)tx[c] * s2) : 0.0;
+    off[1 * g.B + c] = (fl & 2) ? -((double)tx[c + 1] * s2) : 0.0;
+    off[2 * g.B + c] = (fl & 4) ? -((double)ty[c] * s2) : 0.0;
+    off[3 * g.B + c] = (fl & 8) ? -((double)ty[c + sy] * s2) : 0.0;
+    off[4 * g.B + c] = (fl & 16) ? -((double)tz[c] * s2) : 0.0;
+    off[5 * g.B + c] = (fl & 32) ? -((double)tz[c + sz] * s2) : 0.0;
+}
+
+extern "C" int flip_system_download(flip_ctx *ctx, double *off, double *diag, double *rhs) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(ctx->sys_kind >= 0, "flip_system_download: no system assembled");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t B = ctx->B;
+    if (off) {
+        double *tmp = nullptr;
+        FLIP_CHECK(hipMalloc((void **)&tmp, (size_t)B * 6 * 8));
+        k_expand_stencil<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(flip_dims(ctx), ctx->sys_s2, ctx->flags, ctx->term[0],
+                                                                    ctx->term[1], ctx->term[2], tmp);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(off, tmp, (size_t)B * 6 * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(tmp);
+        FLIP_CHECK(e);
+    }
+    if (diag) FLIP_CHECK(hipMemcpyAsync(diag, ctx->diag, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+    if (rhs) FLIP_CHECK(hipMemcpyAsync(rhs, ctx->rhs, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+    FLIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Solver
+
+struct PcgArgs {
+    long long B, sy, sz;
+    int nblk;
+    double s2;
+    const int32_t *chunk_list;
+    const int32_t *n_active; // device scalar
+    const uint8_t *flags;
+    const float *tx, *ty, *tz;
+    const double *diag, *invdiag, *rhs;
+    double *x, *r, *z, *p0, *p1, *ap;
+    double *partial; // [16][FLIP_MAX_PCG_BLOCKS]
+    flip_pcg_scalars *scal;
+    int coupled;
+    double cdt;       // dt of the coupling term
+    double minv[6];
+    const double *J[6];
+};
+
+// The workgroups that share `blockIdx % 8` share an XCD (round-robin dispatch); giving them one
+// contiguous run of the chunk list keeps the stencil's y/z neighbours in that XCD's L2.
+__device__ __forceinline__ void d_chunk_range(const PcgArgs &A, int &lo, int &hi) {
+    const int per = A.nblk >> 3;
+    const int rank = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const long long na = *A.n_active;
+    lo = (int)((na * rank) / A.nblk);
+    hi = (int)((na * (rank + 1)) / A.nblk);
+}
+
+// Sum of the nblk per-workgroup partials of one quantity, identical in every workgroup.
+__device__ __forceinline__ double d_reduce_partials(const double *__restrict__ part, int nblk, double *scratch) {
+    double v = 0.0;
+    for (int q = threadIdx.x; q < nblk; q += FLIP_BLOCK) v += part[q];
+    return d_block_sum(v, scratch);
+}
+
+// Row c of A applied to the vector whose entry at cell q is get(q).
+template <class Get>
+__device__ __forceinline__ double d_apply_row(const PcgArgs &A, long long c, uint8_t fl, double pc, Get get) {
+    double s = A.diag[c] * pc;
+    if (fl & 1) s -= ((double)A.tx[c] * A.s2) * get(c - 1);
+    if (fl & 2) s -= ((double)A.tx[c + 1] * A.s2) * get(c + 1);
+    if (fl & 4) s -= ((double)A.ty[c] * A.s2) * get(c - A.sy);
+    if (fl & 8) s -= ((double)A.ty[c + A.sy] * A.s2) * get(c + A.sy);
+    if (fl & 16) s -= ((double)A.tz[c] * A.s2) * get(c - A.sz);
+    if (fl & 32) s -= ((double)A.tz[c + A.sz] * A.s2) * get(c + A.sz);
+    return s;
+}
+
+__global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_init(PcgArgs A) {
+    __shared__ double scratch[4];
+    int lo, hi;
+    d_chunk_range(A, lo, hi);
+    double rr = 0.0, rz = 0.0;
+    for (int q = lo; q < hi; ++q) {
+        const long long c = (long long)A.chunk_list[q] * FLIP_BLOCK + threadIdx.x;
+        if (c >= A.B) continue;
+        double r = 0.0, z = 0.0;
+        if (A.flags[c] & FLIP_FLAG_ROW) {
+            r = A.rhs[c];
+            z = A.invdiag[c] * r;
+            rr += r * r;
+            rz += r * z;
+        }
+        A.r[c] = r;
+        A.z[c] = z;
+        A.x[c] = 0.0;
+        A.p0[c] = 0.0;
+        A.p1[c] = 0.0;
+        A.ap[c] = 0.0;
+    }
+    rr = d_block_sum(rr, scratch);
+    rz = d_block_sum(rz, scratch);
+    if (threadIdx.x == 0) {
+        A.partial[0 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rr;
+        A.partial[1 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rz;
+    }
+}
+
+__global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_direction(PcgArgs A) {
+    __shared__ double scratch[4];
+    flip_pcg_scalars *S = A.scal;
+    if (S->done) return;
+    const int it = S->it_a;
+    const double rr = d_reduce_partials(A.partial + 0 * FLIP_MAX_PCG_BLOCKS, A.nblk, scratch);
+    const double rz = d_reduce_partials(A.partial + 1 * FLIP_MAX_PCG_BLOCKS, A.nblk, scratch);
+    double beta = 0.0;
+    if (it == 0) {
+        // Eigen: rhsNorm2 == 0 -> x = 0; threshold = max(tol^2 |b|^2, DBL_MIN)
+        double thr = S->tol2 * rr;
+        if (thr < DBL_MIN) thr = DBL_MIN;
+        const bool stop = rr == 0.0 || rr < thr;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            S->rhs_norm2 = rr;
+            S->threshold = thr;
+            S->rr = rr;
+            if (stop) S->done = 1;
+        }
+        if (stop) return;
+    } else {
+        const bool conv = rr < S->threshold;
+        const bool stop = conv || it >= S->max_iter;
+        if (stop) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                S->rr = rr;
+                S->done = conv ? 1 : 2;
+            }
+            return;
+        }
+        beta = rz / S->rz[(it - 1) & 1];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S->rz[it & 1] = rz;
+        S->rr = rr;
+        S->it_b = it;
+    }
+    const double *__restrict__ pold = (it & 1) ? A.p0 : A.p1;
+    double *__restrict__ pnew = (it & 1) ? A.p1 : A.p0;
+    const double *__restrict__ z = A.z;
+    int lo, hi;
+    d_chunk_range(A, lo, hi);
+    double pap = 0.0;
+    double jp[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int q = lo; q < hi; ++q) {
+        const long long c = (long long)A.chunk_list[q] * FLIP_BLOCK + threadIdx.x;
+        if (c >= A.B) continue;
+        const uint8_t fl = A.flags[c];
+        if (!(fl & FLIP_FLAG_ROW)) continue;
+        const double pc = z[c] + beta * pold[c];
+        const double s = d_apply_row(A, c, fl, pc, [&](long long n) { return z[n] + beta * pold[n]; });
+        pnew[c] = pc;
+        A.ap[c] = s;
+        pap += pc * s;
+        if (A.coupled)
+#pragma unroll
+            for (int a = 0; a < 6; ++a) jp[a] += A.J[a][c] * pc;
+    }
+    pap = d_block_sum(pap, scratch);
+    if (threadIdx.x == 0) A.partial[2 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = pap;
+    if (A.coupled) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double v = d_block_sum(jp[a], scratch);
+            if (threadIdx.x == 0) A.partial[(3 + a) * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update(PcgArgs A) {
+    __shared__ double scratch[4];
+    flip_pcg_scalars *S = A.scal;
+    if (S->done) return;
+    const int it = S->it_b;
+    double pap = d_reduce_partials(A.partial + 2 * FLIP_MAX_PCG_BLOCKS, A.nblk, scratch);
+    double gj[6] = { 0, 0, 0, 0, 0, 0 };
+    if (A.coupled) {
+        // p.(A p) with A = A0 + dt J^T Minv J; gj = dt Minv (J p)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double jpa = d_reduce_partials(A.partial + (3 + a) * FLIP_MAX_PCG_BLOCKS, A.nblk, scratch);
+            gj[a] = A.cdt * A.minv[a] * jpa;
+            pap += jpa * gj[a];
+        }
+    }
+    const double alpha = S->rz[it & 1] / pap;
+    const double *__restrict__ p = (it & 1) ? A.p1 : A.p0;
+    int lo, hi;
+    d_chunk_range(A, lo, hi);
+    double rr = 0.0, rz = 0.0;
+    for (int q = lo; q < hi; ++q) {
+        const long long c = (long long)A.chunk_list[q] * FLIP_BLOCK + threadIdx.x;
+        if (c >= A.B) continue;
+        if (!(A.flags[c] & FLIP_FLAG_ROW)) continue;
+        double apv = A.ap[c];
+        if (A.coupled) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) s += A.J[a][c] * gj[a];
+            apv += s;
+        }
+        A.x[c] += alpha * p[c];
+        const double r = A.r[c] - alpha * apv;
+        const double zz = A.invdiag[c] * r;
+        A.r[c] = r;
+        A.z[c] = zz;
+        rr += r * r;
+        rz += r * zz;
+    }
+    rr = d_block_sum(rr, scratch);
+    rz = d_block_sum(rz, scratch);
+    if (threadIdx.x == 0) {
+        A.partial[0 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rr;
+        A.partial[1 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rz;
+        if (blockIdx.x == 0) S->it_a = it + 1;
+    }
+}
+
+static void fill_pcg_args(flip_ctx *ctx, PcgArgs &A) {
+    memset(&A, 0, sizeof A);
+    A.B = ctx->B;
+    A.sy = ctx->g.nx;
+    A.sz = (long long)ctx->g.nx * ctx->g.ny;
+    A.nblk = ctx->pcg_blocks;
+    A.s2 = ctx->sys_s2;
+    A.chunk_list = ctx->chunk_list;
+    A.n_active = ctx->d_counts + 1;
+    A.flags = ctx->flags;
+    A.tx = ctx->term[0]; A.ty = ctx->term[1]; A.tz = ctx->term[2];
+    A.diag = ctx->diag; A.invdiag = ctx->invdiag; A.rhs = ctx->rhs;
+    A.x = ctx->x; A.r = ctx->r; A.z = ctx->z; A.p0 = ctx->pv[0]; A.p1 = ctx->pv[1]; A.ap = ctx->ap;
+    A.partial = ctx->partial;
+    A.scal = ctx->scal;
+    A.coupled = ctx->sys_coupled ? 1 : 0;
+    A.cdt = (double)ctx->sys_dt;
+    for (int a = 0; a < 6; ++a) { A.minv[a] = ctx->obj_minv[a]; A.J[a] = ctx->J[a]; }
+}
+
+extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int precond, flip_pcg_info *info) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(ctx->sys_kind >= 0, "flip_pcg_solve: call flip_build_system first");
+    FLIP_REQUIRE(precond == FLIP_PRECOND_JACOBI, "flip_pcg_solve: only the Jacobi preconditioner is built in this version");
+    FLIP_REQUIRE(tol > 0.0, "flip_pcg_solve: tol must be positive");
+    FLIP_REQUIRE(ctx->pcg_blocks % 8 == 0 && ctx->pcg_blocks <= FLIP_MAX_PCG_BLOCKS, "flip_pcg_solve: bad grid size");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (max_iter <= 0) max_iter = 2 * (ctx->n_rows > 0 ? ctx->n_rows : 1);
+
+    flip_pcg_scalars h;
+    memset(&h, 0, sizeof h);
+    h.tol2 = tol * tol;
+    h.max_iter = max_iter;
+    FLIP_CHECK(hipMemcpyAsync(ctx->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->x, 0, (size_t)ctx->B * 8, st));
+
+    PcgArgs A;
+    fill_pcg_args(ctx, A);
+    const int nblk = ctx->pcg_blocks;
+
+    while (ctx->events.size() < 2 + 2 * 64) {
+        hipEvent_t e;
+        FLIP_CHECK(hipEventCreate(&e));
+        ctx->events.push_back(e);
+    }
+    FLIP_CHECK(hipEventRecord(ctx->events[0], st));
+    k_pcg_init<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+    FLIP_LAUNCH_CHECK();
+
+    const int batch = 32;
+    int launched = 0, n_prof = 0;
+    int32_t done = 0;
+    // one extra direction launch decides convergence after the last update
+    while (!done && launched <= max_iter) {
+        for (int b = 0; b < batch; ++b) {
+            const bool prof = ctx->profiling && n_prof < 64;
+            if (prof) FLIP_CHECK(hipEventRecord(ctx->events[2 + 2 * n_prof], st));
+            k_pcg_direction<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+            if (prof) { FLIP_CHECK(hipEventRecord(ctx->events[3 + 2 * n_prof], st)); ++n_prof; }
+            k_pcg_update<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+        }
+        FLIP_LAUNCH_CHECK();
+        launched += batch;
+        FLIP_CHECK(hipMemcpyAsync(&done, &ctx->scal->done, 4, hipMemcpyDeviceToHost, st));
+        FLIP_CHECK(hipStreamSynchronize(st));
+    }
+    FLIP_CHECK(hipEventRecord(ctx->events[1], st));
+    FLIP_CHECK(hipMemcpyAsync(&h, ctx->scal, sizeof h, hipMemcpyDeviceToHost, st));
+    int32_t counts[2] = { 0, 0 };
+    FLIP_CHECK(hipMemcpyAsync(counts, ctx->d_counts, 8, hipMemcpyDeviceToHost, st));
+    FLIP_CHECK(hipStreamSynchronize(st));
+    ctx->n_active_chunks = counts[1];
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->converged = h.done == 1 ? 1 : 0;
+        info->iterations = h.it_a;
+        info->rows = counts[0];
+        info->active_chunks = counts[1];
+        info->rhs_norm_2 = sqrt(h.rhs_norm2);
+        info->rel_residual_2 = h.rhs_norm2 > 0 ? sqrt(h.rr / h.rhs_norm2) : 0.0;
+        float ms = 0.f;
+        FLIP_CHECK(hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]));
+        info->seconds = (double)ms * 1e-3;
+        double sp = 0.0;
+        int used = 0;
+        for (int q = 0; q < n_prof && q < h.it_a; ++q) {
+            float t = 0.f;
+            FLIP_CHECK(hipEventElapsedTime(&t, ctx->events[2 + 2 * q], ctx->events[3 + 2 * q]));
+            sp += (double)t * 1e-3;
+            ++used;
+        }
+        info->spmv_seconds = sp;
+        info->spmv_launches = used;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Parity hooks
+
+__global__ void k_apply_plain(PcgArgs A, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ jp_out) {
+    __shared__ double scratch[4];
+    double jp[6] = { 0, 0, 0, 0, 0, 0 };
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < A.B; c += (long long)gridDim.x * blockDim.x) {
+        const uint8_t fl = A.flags[c];
+        double s = 0.0;
+        if (fl & FLIP_FLAG_ROW) {
+            s = d_apply_row(A, c, fl, x[c], [&](long long n) { return x[n]; });
+            if (A.coupled)
+#pragma unroll
+                for (int a = 0; a < 6; ++a) jp[a] += A.J[a][c] * x[c];
+        }
+        y[c] = s;
+    }
+    if (A.coupled)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double v = d_block_sum(jp[a], scratch);
+            if (threadIdx.x == 0) jp_out[a * gridDim.x + blockIdx.x] = v;
+        }
+}
+__global__ void k_apply_coupling(PcgArgs A, double g0, double g1, double g2, double g3, double g4, double g5, double *__restrict__ y) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= A.B || !(A.flags[c] & FLIP_FLAG_ROW)) return;
+    y[c] += A.J[0][c] * g0 + A.J[1][c] * g1 + A.J[2][c] * g2 + A.J[3][c] * g3 + A.J[4][c] * g4 + A.J[5][c] * g5;
+}
+
+// J * v over the rows for a dense device vector v (uses ctx->ap as scratch-free reduction target)
+static int coupling_jv(flip_ctx *ctx, const double *dev_v, double *dev_y, double jv[6]) {
+    PcgArgs A;
+    fill_pcg_args(ctx, A);
+    const int nblk = 256;
+    k_apply_plain<<<nblk, FLIP_BLOCK, 0, ctx->stream>>>(A, dev_v, dev_y, ctx->d_vmax);
+    FLIP_LAUNCH_CHECK();
+    for (int a = 0; a < 6; ++a) jv[a] = 0.0;
+    if (A.coupled) {
+        std::vector<double> h(6 * nblk);
+        FLIP_CHECK(hipMemcpyAsync(h.data(), ctx->d_vmax, sizeof(double) * 6 * nblk, hipMemcpyDeviceToHost, ctx->stream));
+        FLIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < nblk; ++b) jv[a] += h[a * nblk + b];
+    }
+    return 0;
+}
+
+int flip_pcg_coupling_jp(flip_ctx *ctx, double jp[6]) {
+    FLIP_REQUIRE(ctx->sys_coupled, "no coupled system assembled");
+    return coupling_jv(ctx, ctx->x, ctx->ap, jp);
+}
+
+extern "C" int flip_apply_operator(flip_ctx *ctx, const double *x_host, double *y_host) {
+    FLIP_REQUIRE(ctx && x_host && y_host, "null argument");
+    FLIP_REQUIRE(ctx->sys_kind >= 0, "flip_apply_operator: call flip_build_system first");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // p0 holds x, p1 receives y (both are solver scratch)
+    FLIP_CHECK(hipMemcpyAsync(ctx->pv[0], x_host, (size_t)ctx->B * 8, hipMemcpyHostToDevice, st));
+    double jv[6];
+    if (int rc = coupling_jv(ctx, ctx->pv[0], ctx->pv[1], jv)) return rc;
+    if (ctx->sys_coupled) {
+        PcgArgs A;
+        fill_pcg_args(ctx, A);
+        double gq[6];
+        for (int a = 0; a < 6; ++a) gq[a] = (double)ctx->sys_dt * ctx->obj_minv[a] * jv[a];
+        k_apply_coupling<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(A, gq[0], gq[1], gq[2], gq[3], gq[4], gq[5], ctx->pv[1]);
+        FLIP_LAUNCH_CHECK();
+    }
+    FLIP_CHECK(hipMemcpyAsync(y_host, ctx->pv[1], (size_t)ctx->B * 8, hipMemcpyDeviceToHost, st));
+    FLIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}

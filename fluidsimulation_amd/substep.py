@@ -1,0 +1,49 @@
+"""The hot-path part of one FLIP substep as a sequence of C-ABI calls.
+
+Mirrors the order of FluidSimulator::advance_flip_pic (src/FluidSimulator.cpp:307-446) for the stages
+that are on the device.  Stages that still belong to the host in the reference's design (fluid sources,
+level set from particles, solid constraint, RK3 advection) are not part of it: the level sets are
+inputs, and the particles move only by the density-projection displacements.
+"""
+from __future__ import annotations
+
+from .binding import FlipContext, PRECOND_JACOBI, SOLVE_DENSITY, SOLVE_DIVERGENCE
+
+
+class FlipSubstep:
+    def __init__(self, ctx: FlipContext, flip_pic_ratio: float = 0.95, tol: float = 1e-15, max_iter: int = 0,
+                 precond: int = PRECOND_JACOBI, density_projection: bool = True):
+        self.ctx = ctx
+        self.ratio = flip_pic_ratio      # main.cpp:167
+        self.tol = tol                   # src/FluidSimulator.cpp:660
+        self.max_iter = max_iter
+        self.precond = precond
+        self.density_projection = density_projection   # DENSITY_CONSTRAINT_PPE, src/FluidSimulator.cpp:31
+        self.info = {}
+
+    def step(self, dt: float) -> dict:
+        c = self.ctx
+        c.bin_particles(want_outside=False)
+        c.p2g()                                   # :337
+        c.mark_valid_from_active()                # :343-345
+        c.extrapolate(2)                          # :349
+        c.update_prev()                           # :367
+        c.add_forces(dt)                          # :373
+        c.index_cells()                           # :486  (weights of the previous substep)
+        c.face_fractions()                        # :488
+        c.density(want_count=False)               # :491
+        c.build_system(SOLVE_DIVERGENCE, dt)      # :505
+        info_div = c.pcg_solve(self.tol, self.max_iter, self.precond)
+        c.project_velocity(dt)                    # :507
+        info_den = None
+        if self.density_projection:
+            c.build_system(SOLVE_DENSITY, dt)     # :521
+            info_den = c.pcg_solve(self.tol, self.max_iter, self.precond)
+            c.project_displacement(dt)            # :523
+        c.extrapolate(2)                          # :398
+        c.update_diff()                           # :416
+        c.g2p(self.ratio)                         # :420
+        if self.density_projection:
+            c.apply_displacements()               # :429
+        self.info = {"divergence": info_div, "density": info_den}
+        return self.info

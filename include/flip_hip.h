@@ -1,0 +1,222 @@
+/*
+ * flip_hip.h -- C ABI of the MI355X (gfx950) FLIP hot-path library, libflip_hip.so.
+ *
+ * The reference (PanagiotisP/FluidSimulation) has no plugin or FFI layer: its boundary is the
+ * C++ class API FluidSimulator / FluidDomain / MacGrid / ParticleSet.  The host classes in
+ * fluidsimulation_amd/host/ keep those signatures and implement their bodies with the entry
+ * points below; every entry point cites the reference member function whose body it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - All state lives in an opaque context bound to one HIP device and one stream.  Calls are
+ *     stream-ordered; only the *_download calls, flip_synchronize and the functions that
+ *     return a host scalar wait for the device.  One context per host thread.
+ *   - Every field is a dense array over one axis-aligned box of cells, x fastest:
+ *         id(i,j,k) = i + nx*(j + ny*k),  index-space coordinate of (i,j,k) = (ox+i,oy+j,oz+k).
+ *     The box stands for the active bounding box of the reference's solid level set
+ *     (src/FluidSimulator.cpp:205,1040,1122).  A read outside the box returns the field's
+ *     background value, as an OpenVDB accessor does for an unallocated voxel.
+ *   - Particle positions are index-space doubles (headers/ParticleSet.h:36-40), passed as
+ *     [n][3] arrays; velocities likewise; mass is float.
+ *   - Return value 0 = success; anything else is an error whose text flip_last_error returns.
+ *     The library never falls back to a CPU path: without a usable HIP device
+ *     flip_ctx_create fails.
+ */
+#ifndef FLIP_HIP_H
+#define FLIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct flip_ctx flip_ctx;
+
+typedef struct flip_grid_desc {
+    int32_t nx, ny, nz;   /* extent of the box in cells                                     */
+    int32_t ox, oy, oz;   /* index-space coordinate of local cell (0,0,0)                   */
+    float dx;             /* voxel size in world units (main.cpp:106)                       */
+    float phi_fluid_bg;   /* fluid level-set background (+3 dx for createLevelSet)          */
+    float phi_solid_bg;   /* solid level-set value outside the box                          */
+    float rest_density;   /* FluidDomain::density (src/FluidDomain.cpp:12)                  */
+} flip_grid_desc;
+
+/* Dense fields that can be uploaded / downloaded.  Element type in brackets. */
+enum flip_field {
+    FLIP_F_PHI_FLUID = 0,   /* [f32]  FluidDomain::fluidLevelSet()                         */
+    FLIP_F_PHI_SOLID = 1,   /* [f32]  FluidDomain::solidLevelSet()                         */
+    FLIP_F_VEL_U = 2,       /* [f64]  MacGrid::velFront(), x component (stored at i-1/2)   */
+    FLIP_F_VEL_V = 3,       /* [f64]                         y component                   */
+    FLIP_F_VEL_W = 4,       /* [f64]                         z component                   */
+    FLIP_F_PREV_U = 5,      /* [f64]  MacGrid::velPrev()                                   */
+    FLIP_F_PREV_V = 6,
+    FLIP_F_PREV_W = 7,
+    FLIP_F_DIFF_U = 8,      /* [f64]  MacGrid::velDiff()                                   */
+    FLIP_F_DIFF_V = 9,
+    FLIP_F_DIFF_W = 10,
+    FLIP_F_DISP_X = 11,     /* [f64]  MacGrid::displacementGrid()                          */
+    FLIP_F_DISP_Y = 12,
+    FLIP_F_DISP_Z = 13,
+    FLIP_F_WEIGHT_U = 14,   /* [f32]  MacGrid::uWeights() (solid face fractions)           */
+    FLIP_F_WEIGHT_V = 15,
+    FLIP_F_WEIGHT_W = 16,
+    FLIP_F_FLUID_WEIGHT_U = 17, /* [f32]  MacGrid::uFluidWeights()                         */
+    FLIP_F_FLUID_WEIGHT_V = 18,
+    FLIP_F_FLUID_WEIGHT_W = 19,
+    FLIP_F_DENSITY = 20,    /* [f32]  MacGrid::densityGrid()                               */
+    FLIP_F_PRESSURE = 21,   /* [f64]  solution of the last pressure solve, 0 off the rows  */
+    FLIP_F_VALID_U = 22,    /* [u8]   MacGrid::validUFront()                               */
+    FLIP_F_VALID_V = 23,
+    FLIP_F_VALID_W = 24,
+    FLIP_F_ACTIVE = 25,     /* [u8]   active voxels of velFront                            */
+    FLIP_F_LABEL = 26,      /* [u8]   1 where the cell has a pressure row                  */
+    FLIP_F_ROW_INDEX = 27,  /* [i32]  row number (ascending cell id) or -1                 */
+    FLIP_F_BAND = 28,       /* [u8]   bit0: particle cells dilated 1, bit1: dilated 2      */
+    FLIP_F_OBJ_WEIGHT_U = 29, /* [f32] SolidObject::uWeights() of the coupled rigid body   */
+    FLIP_F_OBJ_WEIGHT_V = 30,
+    FLIP_F_OBJ_WEIGHT_W = 31,
+    FLIP_F_PHI_OBJECT = 32, /* [f32]  SolidObject::levelSet() of the coupled rigid body    */
+    FLIP_F_COUNT = 33
+};
+
+enum flip_solve_kind {
+    FLIP_SOLVE_DIVERGENCE = 0, /* compute_pressure_divirgence_constraint                   */
+    FLIP_SOLVE_DENSITY = 1     /* compute_pressure_density_constraint                      */
+};
+
+enum flip_precond {
+    FLIP_PRECOND_JACOBI = 0,   /* Eigen DiagonalPreconditioner: what the reference runs    */
+    FLIP_PRECOND_MULTIGRID = 1 /* geometric multigrid V-cycle (GPU-parallel replacement of  */
+                               /* the sequential MIC(0) of headers/pcgsolver/pcg_solver.h)  */
+};
+
+typedef struct flip_pcg_info {
+    int32_t converged;      /* 1 when |r|^2 < tol^2 |b|^2 was reached                      */
+    int32_t iterations;     /* number of operator applications                             */
+    int32_t rows;           /* system size                                                 */
+    int32_t active_chunks;  /* 256-cell chunks swept per kernel                            */
+    double rel_residual_2;  /* sqrt(|r|^2 / |b|^2), r the recurrence residual (as Eigen)   */
+    double rhs_norm_2;      /* |b|                                                         */
+    double seconds;         /* device time of the solve (HIP events on the context stream) */
+    double spmv_seconds;    /* device time spent in the operator kernel, when profiled     */
+    int32_t spmv_launches;  /* launches covered by spmv_seconds                            */
+    int32_t reserved;
+} flip_pcg_info;
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+/* Replaces the construction of FluidDomain/MacGrid storage (src/MacGrid.cpp:3-51,
+ * src/FluidDomain.cpp:14-22).  `stream` is a hipStream_t (NULL = the device's null stream). */
+int flip_ctx_create(const flip_grid_desc *desc, int device, void *stream, flip_ctx **out);
+void flip_ctx_destroy(flip_ctx *ctx);
+/* Text of the last error on this context (or of the last failed flip_ctx_create if ctx==NULL). */
+const char *flip_last_error(const flip_ctx *ctx);
+int flip_synchronize(flip_ctx *ctx);
+int flip_get_desc(const flip_ctx *ctx, flip_grid_desc *out);
+
+/* ---- particles: ParticleSet (headers/ParticleSet.h:43-116) --------------------------------- */
+
+/* ParticleSet::addParticle for a whole set: replaces the std::vector<Particle> store. */
+int flip_particles_upload(flip_ctx *ctx, int64_t n, const double *pos, const double *vel, const float *mass);
+/* ParticleSet::operator[] for a whole set, in upload order.  Any pointer may be NULL. */
+int flip_particles_download(flip_ctx *ctx, double *pos, double *vel);
+int64_t flip_particles_count(const flip_ctx *ctx);
+
+/* Replaces ParticleAtlas::create + createPointMask + dilateActiveValues
+ * (src/FluidSimulator.cpp:83-90, 281-283, 628-630, 686-688, 864-866): counting sort of the
+ * particles by cell floor(pos+0.5), stable in upload order, plus the 1- and 2-cell dilated
+ * occupancy masks (FLIP_F_BAND).  n_outside (may be NULL) receives the number of particles
+ * outside the box; they take part in nothing until they return. */
+int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside);
+/* Parity hook: cell_id[n] in upload order (-1 outside), cell_start[B+1], perm[n] (upload index
+ * of the particle in each sorted slot).  Any pointer may be NULL. */
+int flip_binning_download(flip_ctx *ctx, int32_t *cell_id, int32_t *cell_start, int32_t *perm);
+
+/* ---- dense fields: MacGrid getters/setters (headers/MacGrid.h:47-66) ----------------------- */
+
+int flip_field_upload(flip_ctx *ctx, int field, const void *host);
+int flip_field_download(flip_ctx *ctx, int field, void *host);
+int64_t flip_field_bytes(const flip_ctx *ctx, int field);
+
+/* ---- transfers -------------------------------------------------------------------------------- */
+
+/* FluidSimulator::transfer_from_particles_to_grid (src/FluidSimulator.cpp:71-118) with
+ * GatherTransfer::operator() (src/Functors.cpp:10-45).  Needs flip_bin_particles first.
+ * Result in velFront; FLIP_F_ACTIVE = particle cells dilated 2. */
+int flip_p2g(flip_ctx *ctx);
+/* FluidSimulator::transfer_from_grid_to_particles (src/FluidSimulator.cpp:120-135). */
+int flip_g2p(flip_ctx *ctx, float flip_pic_ratio);
+/* FluidSimulator::apply_particle_displacements (src/FluidSimulator.cpp:137-151). */
+int flip_apply_displacements(flip_ctx *ctx);
+
+/* ---- grid-side glue ------------------------------------------------------------------------- */
+
+/* validU/V/WFront |= topology of velFront (src/FluidSimulator.cpp:343-345). */
+int flip_mark_valid_from_active(flip_ctx *ctx);
+/* FluidSimulator::extrapolate_data (src/FluidSimulator.cpp:181-265). */
+int flip_extrapolate(flip_ctx *ctx, int iterations);
+/* FluidSimulator::add_forces, fluid part (src/FluidSimulator.cpp:460-473). */
+int flip_add_forces(flip_ctx *ctx, float dt);
+/* MacGrid::updatePreviousVelocityBuffer / updateDiffBuffers (src/MacGrid.cpp:55-63). */
+int flip_update_prev(flip_ctx *ctx);
+int flip_update_diff(flip_ctx *ctx);
+/* max over the box of each velocity component (Grid::evalMinMax in compute_cfl,
+ * src/FluidSimulator.cpp:448-458). */
+int flip_velocity_max(flip_ctx *ctx, double out_max[3]);
+
+/* ---- pressure-solve preparation (src/FluidSimulator.cpp:482-492) --------------------------- */
+
+/* FluidSimulator::index_fluid_cells (src/FluidSimulator.cpp:267-305).  Uses the weights
+ * currently stored (the reference calls it before compute_face_fractions). */
+int flip_index_cells(flip_ctx *ctx, int32_t *n_rows);
+/* FluidSimulator::compute_face_fractions (src/FluidSimulator.cpp:527-623) and, when a rigid
+ * body is attached, SolidObject::compute_face_fractions (src/SolidObject.cpp:103-152). */
+int flip_face_fractions(flip_ctx *ctx);
+/* FluidSimulator::compute_density (src/FluidSimulator.cpp:625-652) + DensityCalculator
+ * (src/Functors.cpp:216-266).  n_overdense (may be NULL) = cells above 1.5 rest density, the
+ * cells whose particles the reference re-seeds at random (src/Functors.cpp:277-322). */
+int flip_density(flip_ctx *ctx, int64_t *n_overdense);
+
+/* Attach (phi_object != NULL) or detach the rigid body that is strongly coupled in the
+ * divergence solve: SolidObject (headers/SolidObject.h:9-62).  com = centre of mass in index
+ * space, minv = diagonal of SolidObject::massMatrixInverse, vel = combinedVelocityVector. */
+int flip_solid_object_set(flip_ctx *ctx, const float *phi_object, float phi_object_bg, const double com[3],
+                          const double minv[6], const double vel[6]);
+/* SolidObject::combinedVelocityVector after project_divirgence_constraint (:1095-1100). */
+int flip_solid_object_velocity(flip_ctx *ctx, double vel[6]);
+
+/* ---- solves and projections --------------------------------------------------------------- */
+
+/* Assembly part of compute_pressure_{divirgence,density}_constraint
+ * (src/FluidSimulator.cpp:654-816, 832-990) in matrix-free form. */
+int flip_build_system(flip_ctx *ctx, int kind, float dt);
+/* Rows whose stencil is entirely zero (a labelled cell with no fluid or empty neighbour behind an open
+ * face, e.g. a cell on an edge of the container) make the system singular; with a non-zero right-hand
+ * side it is inconsistent and CG as the reference runs it diverges until the iteration cap.  drop = 1
+ * (default) forces the right-hand side of such rows to zero, which leaves every other unknown's exact
+ * solution unchanged and is what headers/pcgsolver does with a null row (pcg_solver.h:121);
+ * drop = 0 keeps the reference's behaviour.  Applies to the next flip_build_system. */
+int flip_set_null_row_policy(flip_ctx *ctx, int drop);
+/* Parity hook: the assembled stencil on the box: off[6][B] (faces -x,+x,-y,+y,-z,+z), diag[B],
+ * rhs[B]; zero off the rows.  Any pointer may be NULL. */
+int flip_system_download(flip_ctx *ctx, double *off, double *diag, double *rhs);
+/* Solver part (src/FluidSimulator.cpp:822-823, 1006-1007): conjugate gradients from x0 = 0
+ * until |r|^2 < tol^2 |b|^2 or max_iter operator applications (max_iter <= 0: 2*rows, the
+ * Eigen default).  Result in FLIP_F_PRESSURE. */
+int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int precond, flip_pcg_info *info);
+/* y = A x for the assembled system on dense box vectors (parity hook for the SpMV kernel). */
+int flip_apply_operator(flip_ctx *ctx, const double *x_host, double *y_host);
+/* When enabled, flip_pcg_solve brackets a sample of its operator launches with HIP events and
+ * reports their total in flip_pcg_info::spmv_seconds. */
+int flip_set_profiling(flip_ctx *ctx, int enabled);
+
+/* FluidSimulator::project_divirgence_constraint (src/FluidSimulator.cpp:1017-1102). */
+int flip_project_velocity(flip_ctx *ctx, float dt);
+/* FluidSimulator::project_density_constraint (src/FluidSimulator.cpp:1104-1178). */
+int flip_project_displacement(flip_ctx *ctx, float dt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLIP_HIP_H */

@@ -1,0 +1,262 @@
+"""CPU tests of the oracle: against the golden vectors produced by the reference's own headers, against
+its stored stage outputs, and against analytic properties of the path (the reference has no tests; these
+properties are the known-answer tests the path admits)."""
+import numpy as np
+import pytest
+
+from conftest import desc_from_golden, fresh_state
+from fluidsimulation_amd import scenes
+from oracle import Oracle, load_reference_shim
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    sc = scenes.cube_drop(12, ppc=4, seed=3)
+    return sc, Oracle(sc.desc())
+
+
+# ---- pins from the real reference headers (tests/golden/util_tables.npz, pcg_cases.npz) ----------------
+
+def test_trilinear_hat_matches_reference(tiny, golden_util):
+    _, o = tiny
+    got = np.array([o.lib.orc_trilinear_hat(float(x)) for x in golden_util["hat_x"]])
+    assert np.array_equal(got, golden_util["hat_y"])
+
+
+def test_clamp_matches_reference(tiny, golden_util):
+    _, o = tiny
+    got = np.array([o.lib.orc_clamp_f(*map(float, r)) for r in golden_util["clamp_x"]], dtype=np.float32)
+    assert np.array_equal(got, golden_util["clamp_y"])
+
+
+def test_fraction_inside_two_matches_reference(tiny, golden_util):
+    _, o = tiny
+    got = np.array([o.lib.orc_fraction_inside2(float(a), float(b)) for a, b in golden_util["frac2_x"]], dtype=np.float32)
+    assert np.array_equal(got, golden_util["frac2_y"])
+
+
+def test_fraction_inside_four_matches_reference(tiny, golden_util):
+    _, o = tiny
+    got = np.array([o.lib.orc_fraction_inside4(*map(float, r)) for r in golden_util["frac4_x"]], dtype=np.float32)
+    assert np.array_equal(got, golden_util["frac4_y"])
+    # the snapping of util.h:574-579 is exercised
+    assert (got == 0).any() and (got == 1).any() and ((got > 0.1) & (got < 0.9)).any()
+
+
+def test_mic0_pcg_matches_reference_pcgsolver(tiny, golden_pcg):
+    """oracle's restatement of PCGSolver<double>::solve against the real header, bit for bit."""
+    _, o = tiny
+    for k in range(int(golden_pcg["n_cases"])):
+        rowptr, col, val = golden_pcg[f"c{k}_rowptr"], golden_pcg[f"c{k}_col"], golden_pcg[f"c{k}_val"]
+        rhs = golden_pcg[f"c{k}_rhs"]
+        x, ok, res, it, invd = o.pcg_mic0(rowptr, col, val, rhs, 1e-12, 100, want_invdiag=True)
+        meta = golden_pcg[f"c{k}_meta"]
+        assert ok == bool(meta[0]) and it == int(meta[1])
+        assert res == meta[2]
+        assert np.array_equal(invd, golden_pcg[f"c{k}_invdiag"])
+        assert np.array_equal(x, golden_pcg[f"c{k}_x"])
+        y = o.apply_operator(rowptr, col, val, golden_pcg[f"c{k}_spmv_x"])
+        assert np.array_equal(y, golden_pcg[f"c{k}_spmv_y"])
+
+
+def test_eigen_style_cg_agrees_with_reference_pcgsolver(tiny, golden_pcg):
+    """The as-run solver (Jacobi CG, tol 1e-15) and the vendored MIC(0)-PCG solve the same systems."""
+    _, o = tiny
+    for k in range(int(golden_pcg["n_cases"])):
+        rowptr, col, val = golden_pcg[f"c{k}_rowptr"], golden_pcg[f"c{k}_col"], golden_pcg[f"c{k}_val"]
+        x, it, err = o.cg_jacobi(rowptr, col, val, golden_pcg[f"c{k}_rhs"], tol=1e-15)
+        ref = golden_pcg[f"c{k}_x"]
+        assert err < 1e-15 and it < 2 * (rowptr.size - 1)
+        assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+@pytest.mark.skipif(load_reference_shim() is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_live_reference_shim_agrees(tiny):
+    """Where the reference checkout is present, query its headers directly on fresh random inputs."""
+    _, o = tiny
+    ref = load_reference_shim()
+    rng = np.random.default_rng(5)
+    for r in rng.normal(0, 1, (2000, 4)).astype(np.float32):
+        a = tuple(map(float, r))
+        assert o.lib.orc_fraction_inside4(*a) == ref.ref_fraction_inside4_f(*a)
+        assert o.lib.orc_fraction_inside2(a[0], a[1]) == ref.ref_fraction_inside2_f(a[0], a[1])
+        assert o.lib.orc_trilinear_hat(a[2]) == ref.ref_trilinear_hat_d(a[2])
+
+
+# ---- drift detector: stored stage outputs --------------------------------------------------------------
+
+def test_oracle_reproduces_stored_stages(golden_stage):
+    g = golden_stage
+    o = Oracle(desc_from_golden(g))
+    st = dict(pos=g["pos"], vel=g["vel"], mass=g["mass"], phi_fluid=g["phi_fluid"], phi_solid=g["phi_solid"],
+              w=[np.zeros(o.shape, np.float32) for _ in range(3)], valid=[np.zeros(o.shape, np.uint8) for _ in range(3)])
+    out = o.substep(st, float(g["dt"]))
+    assert np.array_equal(out["cell_id"], g["cell_id"]) and np.array_equal(out["perm"], g["perm"])
+    assert np.array_equal(out["label"], g["label"]) and out["n_rows"] == int(g["n_rows"])
+    assert np.array_equal(np.stack(out["p2g"]), g["p2g"])
+    assert np.array_equal(np.stack(out["w"]), g["w"])
+    assert np.array_equal(out["density"], g["density"])
+    assert np.array_equal(out["sys_div"][1], g["sys_div_diag"]) and np.array_equal(out["sys_div"][0], g["sys_div_off"])
+    assert np.allclose(np.stack(out["projected"]), g["projected"], rtol=0, atol=1e-12)
+    assert np.allclose(out["new_pos"], g["new_pos"], rtol=0, atol=1e-12)
+
+
+# ---- analytic / property tests ------------------------------------------------------------------------
+
+def test_binning_is_a_stable_counting_sort(tiny):
+    sc, o = tiny
+    pos = sc.pos.copy()
+    pos[:5] += 1000.0  # five particles far outside the box
+    cell_id, cell_start, perm, n_out = o.bin_particles(pos)
+    assert n_out == 5 and (cell_id[:5] == -1).all()
+    inside = perm[: cell_start[-1]]
+    keys = cell_id[inside]
+    assert (np.diff(keys) >= 0).all()                      # sorted by cell
+    same = np.diff(keys) == 0
+    assert (np.diff(inside)[same] > 0).all()               # upload order kept inside a cell
+    ijk = np.floor(pos[5:] + 0.5).astype(int) - np.array(sc.origin)
+    lin = ijk[:, 0] + sc.dims[0] * (ijk[:, 1] + sc.dims[1] * ijk[:, 2])
+    assert np.array_equal(lin, cell_id[5:])
+    assert sorted(perm.tolist()) == list(range(pos.shape[0]))
+
+
+def test_empty_particle_set(tiny):
+    sc, o = tiny
+    cell_id, cell_start, perm, n_out = o.bin_particles(np.zeros((0, 3)))
+    assert n_out == 0 and cell_start.max() == 0
+    band = o.particle_mask(cell_start, 2)
+    u, v, w = o.p2g(np.zeros((0, 3)), np.zeros((0, 3)), cell_start, perm, band)
+    assert not band.any() and not u.any()
+
+
+def test_p2g_of_uniform_velocity_returns_it(tiny):
+    sc, o = tiny
+    vel = np.tile(np.array([0.3, -1.2, 0.7]), (sc.pos.shape[0], 1))
+    _, cell_start, perm, _ = o.bin_particles(sc.pos)
+    band = o.particle_mask(cell_start, 2)
+    u, v, w = o.p2g(sc.pos, vel, cell_start, perm, band)
+    for f, val in zip((u, v, w), (0.3, -1.2, 0.7)):
+        hit = f != 0
+        assert hit.any() and np.allclose(f[hit], val, rtol=1e-12)
+        assert not f[band == 0].any()
+
+
+def test_p2g_gather_truncates_the_staggered_kernel(tiny):
+    """A particle 1.25 cells below a u-face in x has hat(d+0.5) = 0.75 but is outside the query box."""
+    sc, o = tiny
+    c = np.array(sc.origin) + np.array(sc.dims) // 2
+    pos = (c + np.array([-1.25, 0.0, 0.0]))[None, :].astype(np.float64)
+    vel = np.array([[2.0, 0.0, 0.0]])
+    _, cell_start, perm, _ = o.bin_particles(pos)
+    band = o.particle_mask(cell_start, 2)
+    u, _, _ = o.p2g(pos, vel, cell_start, perm, band)
+    loc = tuple((c - np.array(sc.origin))[::-1])
+    assert u[loc] == 0.0                       # d = -1.25 is not gathered
+    left = (loc[0], loc[1], loc[2] - 1)
+    assert u[left] == pytest.approx(2.0)       # d = -0.25: weight 0.75, normalised
+
+
+def test_g2p_with_ratio_zero_is_pic_and_linear_fields_are_exact(tiny):
+    sc, o = tiny
+    x, y, z = sc.cell_coords()
+    # u lives at (i-1/2, j, k): a field linear in the sample position is reproduced exactly by trilinear sampling
+    u = np.ascontiguousarray(np.broadcast_to(2.0 * (x - 0.5) + 0.5 * y - z, o.shape), dtype=np.float64)
+    v = np.ascontiguousarray(np.broadcast_to(x - 3.0 * (y - 0.5) + 0.25 * z, o.shape), dtype=np.float64)
+    w = np.ascontiguousarray(np.broadcast_to(-x + y + 1.5 * (z - 0.5), o.shape), dtype=np.float64)
+    zero = [np.zeros(o.shape) for _ in range(3)]
+    new = o.g2p(sc.pos, sc.vel + 5.0, (u, v, w), zero, 0.0)
+    p = sc.pos
+    assert np.allclose(new[:, 0], 2.0 * p[:, 0] + 0.5 * p[:, 1] - p[:, 2], atol=1e-11)
+    assert np.allclose(new[:, 1], p[:, 0] - 3.0 * p[:, 1] + 0.25 * p[:, 2], atol=1e-11)
+    assert np.allclose(new[:, 2], -p[:, 0] + p[:, 1] + 1.5 * p[:, 2], atol=1e-11)
+    # ratio 1, zero diff: pure FLIP keeps the particle velocity
+    keep = o.g2p(sc.pos, sc.vel + 5.0, (u, v, w), zero, 1.0)
+    assert np.allclose(keep, sc.vel + 5.0)
+
+
+def test_first_substep_of_a_falling_block_is_pressure_free(tiny):
+    """Uniform free fall: the divergence right-hand side is zero, so p = 0 and the block just accelerates."""
+    sc, o = tiny
+    out = o.substep(fresh_state(sc, o), 0.01)
+    assert out["it_div"] == 0 and not out["p_div"].any()
+    assert np.allclose(out["new_vel"][:, 1], -9.81 * 0.01, rtol=1e-6)
+    assert np.abs(out["new_vel"][:, [0, 2]]).max() == 0
+
+
+def test_projection_removes_fv_divergence(tiny):
+    """After project_divirgence_constraint the FV divergence sum_f (1-W_f) u_f.n of every interior fluid row
+    vanishes to solver precision (float pressure gradient -> ~1e-6 relative)."""
+    sc, o = tiny
+    rng = np.random.default_rng(1)
+    out = o.substep(fresh_state(sc, o, vel=rng.normal(0, 0.3, sc.pos.shape)), 0.005, density_projection=False)
+    u, v, w = out["projected"]
+    wu, wv, ww = out["w"]
+    lab = out["label"].astype(bool)
+    phi = sc.phi_fluid
+    interior = lab.copy()
+    for ax in range(3):                # all six neighbours are liquid: no ghost-fluid faces
+        for sh in (1, -1):
+            interior &= np.roll(phi, sh, axis=ax) < 0
+    div = ((1 - wu) * u - np.roll((1 - wu) * u, -1, axis=2) + (1 - wv) * v - np.roll((1 - wv) * v, -1, axis=1)
+           + (1 - ww) * w - np.roll((1 - ww) * w, -1, axis=0))
+    before = out["sys_div"][2][interior] / float(np.float32(sc.dx) ** 2)
+    assert interior.sum() > 20
+    assert np.abs(div[interior]).max() < 2e-5 * max(np.abs(before).max(), 1e-3)
+
+
+def test_hydrostatic_column_pressure(tiny):
+    """A block at rest on the floor under one gravity step: interior pressure follows p = rho g h."""
+    sc = scenes.cube_drop(16, ppc=8, seed=11)
+    o = Oracle(sc.desc())
+    dt = 0.01
+    st = fresh_state(sc, o)
+    cell_id, cell_start, perm, _ = o.bin_particles(sc.pos)
+    pm1, pm2 = o.particle_mask(cell_start, 1), o.particle_mask(cell_start, 2)
+    wm = o.weight_mask(sc.phi_fluid, sc.phi_fluid_bg)
+    w = o.face_fractions(sc.phi_solid, sc.phi_solid_bg, wm)
+    o.combine_weights(w, None)
+    label, index, n = o.index_cells(pm1, sc.phi_fluid, sc.phi_solid, st["w"])
+    zero = np.zeros(o.shape)
+    vy = np.where(pm2 > 0, -9.81 * dt, 0.0)
+    # close the floor: no flow through a face whose lower cell is not inside the container
+    # (the container wall passes through the centres of the cells j = 1, main.cpp:123)
+    vy = np.where(np.roll(sc.phi_solid, 1, axis=1) <= 0, 0.0, vy)
+    off, diag, rhs = o.build_system(0, dt, label, sc.phi_fluid, sc.phi_solid, w, uvw=(zero, vy, zero))
+    rowptr, col, val, b = o.to_csr(index, off, diag, rhs)
+    p, it, err = o.cg_jacobi(rowptr, col, val, b)
+    assert err < 1e-15
+    # pressure difference between vertically adjacent interior rows = rho * g * dx
+    P = np.zeros(o.shape)
+    P[index >= 0] = p[index[index >= 0]]
+    deep = (index >= 0) & (np.roll(index, -1, axis=1) >= 0) & (np.roll(index, -2, axis=1) >= 0) & (np.roll(index, 1, axis=1) >= 0)
+    nx, ny, nz = sc.dims
+    deep[:, :, : nx // 2 - 1] = False
+    deep[:, :, nx // 2 + 2:] = False
+    deep[: nz // 2 - 1] = False
+    deep[nz // 2 + 2:] = False
+    grad = (P - np.roll(P, -1, axis=1))[deep]
+    expect = 1000.0 * 9.81 * float(sc.dx)
+    assert grad.size > 3 and np.allclose(grad, expect, rtol=5e-2)
+
+
+def test_dropping_null_rows_keeps_the_solution_of_the_other_rows():
+    sc = scenes.cube_drop(16, ppc=4, seed=21)
+    o = Oracle(sc.desc())
+    st = fresh_state(sc, o)
+    out = o.substep(st, 0.01)
+    st2 = dict(st, w=out["w"], valid=out["valid"], pos=out["new_pos"], vel=out["new_vel"],
+               phi_fluid=scenes.fluid_levelset(sc, out["new_pos"]))
+    out2 = o.substep(st2, 0.01, max_iter=4000, density_projection=False)
+    off, diag, rhs, b = out2["sys_div"]
+    rowptr, col, val, bb = o.to_csr(out2["index"], off, diag, rhs)
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    A = sp.csr_matrix((val, col, rowptr))
+    d = A.diagonal()
+    null = d == 0
+    assert null.any(), "the scene is meant to produce all-zero rows on the container edges"
+    assert out2["err_div"] < 1e-15
+    keep = ~null
+    exact = spl.spsolve(A[keep][:, keep].tocsc(), bb[keep])
+    assert np.abs(out2["p_div"][keep] - exact).max() <= 1e-9 * np.abs(exact).max()
+    assert not out2["p_div"][null].any()
