@@ -29,10 +29,10 @@ class PcgInfo(C.Structure):
     _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("rows", C.c_int32),
                 ("active_chunks", C.c_int32), ("rel_residual_2", C.c_double), ("rhs_norm_2", C.c_double),
                 ("seconds", C.c_double), ("spmv_seconds", C.c_double), ("spmv_launches", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("dependent_rows", C.c_int32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 # enum flip_field: name -> (id, dtype)
@@ -62,7 +62,7 @@ EXPORTS = [
     "flip_apply_displacements", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
     "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
-    "flip_set_null_row_policy", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_project_velocity",
+    "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_project_velocity",
     "flip_project_displacement",
 ]
 
@@ -109,7 +109,7 @@ def load_library(path: str = LIB_PATH):
         "flip_solid_object_set": (C.c_int, [vp, vp, f32, vp, vp, vp]),
         "flip_solid_object_velocity": (C.c_int, [vp, P(f64)]),
         "flip_build_system": (C.c_int, [vp, C.c_int, f32]),
-        "flip_set_null_row_policy": (C.c_int, [vp, C.c_int]),
+        "flip_set_system_options": (C.c_int, [vp, C.c_int, C.c_int]),
         "flip_system_download": (C.c_int, [vp, vp, vp, vp]),
         "flip_pcg_solve": (C.c_int, [vp, f64, i32, C.c_int, P(PcgInfo)]),
         "flip_apply_operator": (C.c_int, [vp, vp, vp]),
@@ -269,8 +269,9 @@ class FlipContext:
     def build_system(self, kind: int, dt: float):
         self._check(self.lib.flip_build_system(self.h, kind, dt))
 
-    def set_null_row_policy(self, drop: bool):
-        self._check(self.lib.flip_set_null_row_policy(self.h, 1 if drop else 0))
+    def set_system_options(self, drop_null_rows: bool = True, eliminate_dependent_rows: bool = True):
+        self._check(self.lib.flip_set_system_options(self.h, 1 if drop_null_rows else 0,
+                                                     1 if eliminate_dependent_rows else 0))
 
     def download_system(self):
         off = np.empty((6,) + self.shape, dtype=np.float64)

@@ -18,6 +18,7 @@
 
 // Per-cell flag byte of the assembled system.
 #define FLIP_FLAG_ROW 0x40u      // the cell has a row
+#define FLIP_FLAG_DEP 0x80u      // dependent row: no other row refers to it; solved by substitution after CG
 // bits 0..5: the off-diagonal toward face f (-x,+x,-y,+y,-z,+z) is present
 
 struct flip_pcg_scalars {
@@ -80,6 +81,8 @@ struct flip_ctx {
     double sys_s2 = 1.0;            // dx^2 scaling of the divergence system
     bool sys_coupled = false;
     bool drop_null_rows = true;     // rhs of all-zero rows forced to 0
+    bool eliminate_dep = true;      // rows of cells with phi_fluid >= 0 are eliminated from the CG system
+    bool sys_eliminated = false;    // the assembled system carries FLIP_FLAG_DEP rows
     float *term[3] = {};            // (1 - W) * scale at the low x/y/z face of every cell
     uint8_t *flags = nullptr;
     double *diag = nullptr, *invdiag = nullptr, *rhs = nullptr;

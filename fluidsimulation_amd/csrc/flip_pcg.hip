@@ -36,6 +36,8 @@ struct BuildArgs {
     // rigid-body coupling (kind 0 only)
     int coupled;
     int drop_null;
+    int eliminate;
+    int32_t *counters; // [4] dependent rows, [5] dependent rows with a non-zero rigid-body entry
     const float *ou, *ov, *ow;
     double com[3], minv[6], vel[6];
     double *J[6];
@@ -122,6 +124,14 @@ __global__ void k_build_system(BuildArgs A) {
             }
             inv = dfull != 0 ? 1.0 / dfull : 1.0; // Eigen DiagonalPreconditioner
             if (A.drop_null && dfull == 0) rh = 0.0; // all-zero row: nothing to solve for
+            if (A.eliminate && !(phi_c < 0)) {
+                // A labelled cell that is not liquid enters no other row (an off-diagonal needs phi < 0 at the
+                // neighbour), so the matrix is block lower triangular: [liquid rows | 0 ; C | diag].
+                fl |= FLIP_FLAG_DEP;
+                atomicAdd(A.counters + 4, 1);
+                if (A.coupled && (Jr[0] != 0 || Jr[1] != 0 || Jr[2] != 0 || Jr[3] != 0 || Jr[4] != 0 || Jr[5] != 0))
+                    atomicAdd(A.counters + 5, 1);
+            }
         }
         A.flags[c] = fl;
         A.diag[c] = dg;
@@ -145,9 +155,10 @@ __global__ void k_compact_chunks(int n_chunks, const int32_t *__restrict__ flag_
     if (flag_scan[q + 1] > flag_scan[q]) list[flag_scan[q]] = q;
 }
 
-extern "C" int flip_set_null_row_policy(flip_ctx *ctx, int drop) {
+extern "C" int flip_set_system_options(flip_ctx *ctx, int drop_null_rows, int eliminate_dependent_rows) {
     FLIP_REQUIRE(ctx, "null context");
-    ctx->drop_null_rows = drop != 0;
+    ctx->drop_null_rows = drop_null_rows != 0;
+    ctx->eliminate_dep = eliminate_dependent_rows != 0;
     return 0;
 }
 
@@ -179,12 +190,28 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     A.chunk_flag = ctx->chunk_flag;
     A.coupled = (kind == 0 && ctx->has_obj) ? 1 : 0;
     A.drop_null = ctx->drop_null_rows ? 1 : 0;
+    A.eliminate = ctx->eliminate_dep ? 1 : 0;
+    A.counters = ctx->d_counts;
     A.ou = ctx->owgt[0]; A.ov = ctx->owgt[1]; A.ow = ctx->owgt[2];
     for (int a = 0; a < 3; ++a) A.com[a] = ctx->obj_com[a];
     for (int a = 0; a < 6; ++a) { A.minv[a] = ctx->obj_minv[a]; A.vel[a] = ctx->obj_vel[a]; A.J[a] = ctx->J[a]; }
     FLIP_CHECK(hipMemsetAsync(ctx->chunk_flag + ctx->n_chunks, 0, 4, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 4, 0, 8, st));
     k_build_system<<<ctx->n_chunks, FLIP_BLOCK, 0, st>>>(A);
     FLIP_LAUNCH_CHECK();
+    if (A.eliminate && A.coupled) {
+        // The rank-6 term couples every row with a non-zero rigid-body entry to every other such row; if a
+        // dependent row has one, the block-triangular structure is gone and the system is solved whole.
+        int32_t cnt[2] = { 0, 0 };
+        FLIP_CHECK(hipMemcpyAsync(cnt, ctx->d_counts + 4, 8, hipMemcpyDeviceToHost, st));
+        FLIP_CHECK(hipStreamSynchronize(st));
+        if (cnt[1] > 0) {
+            A.eliminate = 0;
+            FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 4, 0, 8, st));
+            k_build_system<<<ctx->n_chunks, FLIP_BLOCK, 0, st>>>(A);
+            FLIP_LAUNCH_CHECK();
+        }
+    }
     if (int rc = flip_exclusive_scan(ctx, ctx->chunk_flag, ctx->n_chunks + 1)) return rc;
     k_compact_chunks<<<flip_grid_blocks(ctx->n_chunks), FLIP_BLOCK, 0, st>>>(ctx->n_chunks, ctx->chunk_flag, nullptr, ctx->chunk_list);
     FLIP_LAUNCH_CHECK();
@@ -193,6 +220,7 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     ctx->sys_dt = dt;
     ctx->sys_s2 = A.s2;
     ctx->sys_coupled = A.coupled != 0;
+    ctx->sys_eliminated = A.eliminate != 0;
     return 0;
 }
 
@@ -294,7 +322,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_init(PcgArgs A) {
         const long long c = (long long)A.chunk_list[q] * FLIP_BLOCK + threadIdx.x;
         if (c >= A.B) continue;
         double r = 0.0, z = 0.0;
-        if (A.flags[c] & FLIP_FLAG_ROW) {
+        if ((A.flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW) {
             r = A.rhs[c];
             z = A.invdiag[c] * r;
             rr += r * r;
@@ -363,7 +391,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_direction(PcgArgs A) {
         const long long c = (long long)A.chunk_list[q] * FLIP_BLOCK + threadIdx.x;
         if (c >= A.B) continue;
         const uint8_t fl = A.flags[c];
-        if (!(fl & FLIP_FLAG_ROW)) continue;
+        if ((fl & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) != FLIP_FLAG_ROW) continue;
         const double pc = z[c] + beta * pold[c];
         const double s = d_apply_row(A, c, fl, pc, [&](long long n) { return z[n] + beta * pold[n]; });
         pnew[c] = pc;
@@ -408,7 +436,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update(PcgArgs A) {
     for (int q = lo; q < hi; ++q) {
         const long long c = (long long)A.chunk_list[q] * FLIP_BLOCK + threadIdx.x;
         if (c >= A.B) continue;
-        if (!(A.flags[c] & FLIP_FLAG_ROW)) continue;
+        if ((A.flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) != FLIP_FLAG_ROW) continue;
         double apv = A.ap[c];
         if (A.coupled) {
             double s = 0.0;
@@ -430,6 +458,21 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update(PcgArgs A) {
         A.partial[0 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rr;
         A.partial[1 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rz;
         if (blockIdx.x == 0) S->it_a = it + 1;
+    }
+}
+
+// Back-substitution of the dependent rows: diag x_c = b_c - sum_f A(c,n_f) x_n, x_c = 0 for an all-zero row.
+__global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_dependent(PcgArgs A) {
+    int lo, hi;
+    d_chunk_range(A, lo, hi);
+    for (int q = lo; q < hi; ++q) {
+        const long long c = (long long)A.chunk_list[q] * FLIP_BLOCK + threadIdx.x;
+        if (c >= A.B) continue;
+        const uint8_t fl = A.flags[c];
+        if ((fl & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) != (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) continue;
+        const double d = A.diag[c];
+        const double s = d_apply_row(A, c, fl, 0.0, [&](long long n) { return A.x[n]; });
+        A.x[c] = d != 0 ? (A.rhs[c] - s) / d : 0.0;
     }
 }
 
@@ -500,10 +543,14 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
         FLIP_CHECK(hipMemcpyAsync(&done, &ctx->scal->done, 4, hipMemcpyDeviceToHost, st));
         FLIP_CHECK(hipStreamSynchronize(st));
     }
+    if (ctx->sys_eliminated) {
+        k_pcg_dependent<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+        FLIP_LAUNCH_CHECK();
+    }
     FLIP_CHECK(hipEventRecord(ctx->events[1], st));
     FLIP_CHECK(hipMemcpyAsync(&h, ctx->scal, sizeof h, hipMemcpyDeviceToHost, st));
-    int32_t counts[2] = { 0, 0 };
-    FLIP_CHECK(hipMemcpyAsync(counts, ctx->d_counts, 8, hipMemcpyDeviceToHost, st));
+    int32_t counts[6] = { 0, 0, 0, 0, 0, 0 };
+    FLIP_CHECK(hipMemcpyAsync(counts, ctx->d_counts, 24, hipMemcpyDeviceToHost, st));
     FLIP_CHECK(hipStreamSynchronize(st));
     ctx->n_active_chunks = counts[1];
     if (info) {
@@ -512,6 +559,7 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
         info->iterations = h.it_a;
         info->rows = counts[0];
         info->active_chunks = counts[1];
+        info->dependent_rows = counts[4];
         info->rhs_norm_2 = sqrt(h.rhs_norm2);
         info->rel_residual_2 = h.rhs_norm2 > 0 ? sqrt(h.rr / h.rhs_norm2) : 0.0;
         float ms = 0.f;

@@ -101,7 +101,7 @@ typedef struct flip_pcg_info {
     double seconds;         /* device time of the solve (HIP events on the context stream) */
     double spmv_seconds;    /* device time spent in the operator kernel, when profiled     */
     int32_t spmv_launches;  /* launches covered by spmv_seconds                            */
-    int32_t reserved;
+    int32_t dependent_rows; /* rows solved by substitution after CG (see flip_set_system_options) */
 } flip_pcg_info;
 
 /* ---- context ---------------------------------------------------------------------------- */
@@ -191,13 +191,20 @@ int flip_solid_object_velocity(flip_ctx *ctx, double vel[6]);
 /* Assembly part of compute_pressure_{divirgence,density}_constraint
  * (src/FluidSimulator.cpp:654-816, 832-990) in matrix-free form. */
 int flip_build_system(flip_ctx *ctx, int kind, float dt);
-/* Rows whose stencil is entirely zero (a labelled cell with no fluid or empty neighbour behind an open
- * face, e.g. a cell on an edge of the container) make the system singular; with a non-zero right-hand
- * side it is inconsistent and CG as the reference runs it diverges until the iteration cap.  drop = 1
- * (default) forces the right-hand side of such rows to zero, which leaves every other unknown's exact
- * solution unchanged and is what headers/pcgsolver does with a null row (pcg_solver.h:121);
- * drop = 0 keeps the reference's behaviour.  Applies to the next flip_build_system. */
-int flip_set_null_row_policy(flip_ctx *ctx, int drop);
+/* Two properties of the reference's system decide whether its CG can converge at all; both options default
+ * to 1 and apply to the next flip_build_system.
+ *   drop_null_rows: a labelled cell with no liquid or empty neighbour behind an open face (e.g. on an edge of
+ *     the container) has an all-zero row.  With a non-zero right-hand side the system is inconsistent and CG as
+ *     the reference runs it diverges until the iteration cap.  1 forces the right-hand side of such rows to
+ *     zero, which leaves every other unknown's exact solution unchanged and is what headers/pcgsolver does
+ *     with a null row (pcg_solver.h:121); 0 keeps the reference's behaviour.
+ *   eliminate_dependent_rows: a labelled cell with phi_fluid >= 0 (labelled through the partial-face rule of
+ *     src/FluidSimulator.cpp:297-300) refers to its liquid neighbours, but no row refers to it, so the matrix
+ *     is block lower triangular and not symmetric.  1 runs CG on the symmetric liquid block and obtains the
+ *     dependent rows by substitution: the same solution of the same A p = b, reached reliably.  0 runs CG on
+ *     the whole non-symmetric matrix as the reference does.  With a rigid body whose coupling rows touch a
+ *     dependent row the library solves the whole system regardless. */
+int flip_set_system_options(flip_ctx *ctx, int drop_null_rows, int eliminate_dependent_rows);
 /* Parity hook: the assembled stencil on the box: off[6][B] (faces -x,+x,-y,+y,-z,+z), diag[B],
  * rhs[B]; zero off the rows.  Any pointer may be NULL. */
 int flip_system_download(flip_ctx *ctx, double *off, double *diag, double *rhs);

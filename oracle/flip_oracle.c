@@ -758,6 +758,57 @@ done:
     return it;
 }
 
+/* NOT a restatement of reference code: the same system A p = b solved by block elimination.  */
+/* A row of a labelled cell with phi_fluid >= 0 (dep[i] != 0) refers to liquid rows, but no row  */
+/* refers to it, so A = [L 0; C D] with L symmetric and D diagonal.  CG (the iteration above)    */
+/* runs on L; the dependent rows follow by substitution.  Where the as-run iteration converges   */
+/* both give the same p; where it cannot (non-symmetric matrix), this is the checker.  A rigid    */
+/* body's J must vanish on the dependent rows (the caller checks).  Returns the CG iterations.  */
+ORC_EXPORT int32_t orc_cg_eliminated(int32_t n, const int32_t *rowptr, const int32_t *col, const double *val,
+                                     const uint8_t *dep, const double *J, const double *minv, double dt,
+                                     const double *rhs, double tol, int32_t max_iter, int drop_null_rows, double *x,
+                                     double *err) {
+    int32_t *map = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    int32_t m = 0;
+    for (int32_t i = 0; i < n; ++i) map[i] = dep[i] ? -1 : m++;
+    int32_t *rp = (int32_t *)malloc(sizeof(int32_t) * ((size_t)m + 1));
+    int32_t *cc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rowptr[n] > 0 ? rowptr[n] : 1));
+    double *vv = (double *)malloc(sizeof(double) * (size_t)(rowptr[n] > 0 ? rowptr[n] : 1));
+    double *bb = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+    double *xx = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+    double *JJ = J ? (double *)malloc(sizeof(double) * 6 * (size_t)(m > 0 ? m : 1)) : NULL;
+    int32_t nnz = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        if (dep[i]) continue;
+        rp[map[i]] = nnz;
+        for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+            if (map[col[q]] < 0) continue; /* cannot happen: a liquid row refers to liquid rows only */
+            cc[nnz] = map[col[q]];
+            vv[nnz++] = val[q];
+        }
+        bb[map[i]] = rhs[i];
+        if (J)
+            for (int a = 0; a < 6; ++a) JJ[(int64_t)a * m + map[i]] = J[(int64_t)a * n + i];
+    }
+    rp[m] = nnz;
+    int32_t it = 0;
+    *err = 0;
+    if (m > 0) it = orc_cg_jacobi(m, rp, cc, vv, JJ, minv, dt, bb, tol, max_iter, drop_null_rows, xx, err);
+    for (int32_t i = 0; i < n; ++i)
+        if (!dep[i]) x[i] = xx[map[i]];
+    for (int32_t i = 0; i < n; ++i) {
+        if (!dep[i]) continue;
+        double d = 0, s = 0;
+        for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+            if (col[q] == i) d += val[q];
+            else s += val[q] * x[col[q]];
+        }
+        x[i] = d != 0 ? (rhs[i] - s) / d : 0.0;
+    }
+    free(map); free(rp); free(cc); free(vv); free(bb); free(xx); free(JJ);
+    return it;
+}
+
 /* headers/pcgsolver/pcg_solver.h:80-182: modified incomplete Cholesky level 0 of the     */
 /* lower triangle, columns stored CSC.  The matrix is CSR with ascending columns and is    */
 /* assumed structurally symmetric, as the header assumes.                                 */

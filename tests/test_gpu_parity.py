@@ -256,6 +256,41 @@ def test_second_substep_with_stale_weights_and_wall_rows():
         assert rel_linf(vel2, out2["new_vel"]) < VEL_RTOL
 
 
+def test_as_run_iteration_and_elimination_agree_on_the_gpu():
+    """The same second-substep system solved both ways by the library (options of flip_set_system_options):
+    CG over the whole non-symmetric matrix, as the reference runs it, and CG on the liquid block followed by
+    substitution.  Same pressure, the oracle's in both cases."""
+    sc = scenes.cube_drop(16, ppc=4, seed=21)
+    o = Oracle(sc.desc())
+    st = fresh_state(sc, o)
+    out1 = o.substep(st, 0.01)
+    phi2 = scenes.fluid_levelset(sc, out1["new_pos"])
+    st2 = dict(st, w=out1["w"], valid=out1["valid"], pos=out1["new_pos"], vel=out1["new_vel"], phi_fluid=phi2)
+    ref = o.substep(st2, 0.01, max_iter=20000, density_projection=False, eliminate=False)
+    assert ref["err_div"] < RES_TOL and ref["dep"].any()
+    lab = ref["label"].astype(bool)
+    got = {}
+    for eliminate in (False, True):
+        with FlipContext(sc.desc()) as ctx:
+            ctx.set_system_options(True, eliminate)
+            ctx.upload("phi_solid", sc.phi_solid); ctx.upload("phi_fluid", phi2)
+            ctx.upload_particles(out1["new_pos"], out1["new_vel"], sc.mass)
+            for name, arr in zip(("weight_u", "weight_v", "weight_w"), out1["w"]):
+                ctx.upload(name, arr)
+            for name, arr in zip(("valid_u", "valid_v", "valid_w"), out1["valid"]):
+                ctx.upload(name, arr)
+            ctx.bin_particles(); ctx.p2g(); ctx.mark_valid_from_active(); ctx.extrapolate(2); ctx.update_prev()
+            ctx.add_forces(0.01); ctx.index_cells(); ctx.face_fractions(); ctx.density()
+            ctx.build_system(SOLVE_DIVERGENCE, 0.01)
+            info = ctx.pcg_solve(RES_TOL, 20000)
+            assert info["converged"] == 1
+            assert info["dependent_rows"] == (int(ref["dep"].sum()) if eliminate else 0)
+            got[eliminate] = (ctx.download("pressure")[lab], info["iterations"])
+    assert rel_linf(got[False][0], ref["p_div"]) < 1e-7
+    assert rel_linf(got[True][0], ref["p_div"]) < 1e-7
+    assert got[True][1] < got[False][1]
+
+
 def test_rigid_body_coupling():
     """Config 3 in small: a sphere strongly coupled through J^T M^-1 J (src/FluidSimulator.cpp:810-816)."""
     sc = scenes.cube_drop(24, ppc=4, seed=9)
