@@ -26,10 +26,10 @@ class GridDesc(C.Structure):
 
 
 class PcgInfo(C.Structure):
-    _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("rows", C.c_int32),
+    _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("rows", C.c_int32), ("cg_rows", C.c_int32),
                 ("active_chunks", C.c_int32), ("rel_residual_2", C.c_double), ("rhs_norm_2", C.c_double),
                 ("seconds", C.c_double), ("spmv_seconds", C.c_double), ("spmv_launches", C.c_int32),
-                ("dependent_rows", C.c_int32)]
+                ("dependent_rows", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

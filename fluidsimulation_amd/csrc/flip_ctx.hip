@@ -64,7 +64,14 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
     dfree(c->density); dfree(c->active); dfree(c->active_back); dfree(c->label); dfree(c->band);
     dfree(c->seed); dfree(c->tmp_u8); dfree(c->row_index);
     dfree(c->flags); dfree(c->diag); dfree(c->invdiag); dfree(c->rhs);
-    dfree(c->x); dfree(c->r); dfree(c->z); dfree(c->pv[0]); dfree(c->pv[1]); dfree(c->ap);
+    {   // padded solver arrays: the stored pointers are offset by c->pad
+        double **dp[] = { &c->x, &c->r, &c->z, &c->pv[0], &c->pv[1], &c->ap, &c->cg_diag, &c->cg_inv };
+        for (double **q : dp)
+            if (*q) { (void)hipFree(*q - c->pad); *q = nullptr; }
+        for (int a = 0; a < 3; ++a)
+            if (c->cg_c[a]) { (void)hipFree(c->cg_c[a] - c->pad); c->cg_c[a] = nullptr; }
+    }
+    dfree(c->cg_scan); dfree(c->cg_rows);
     dfree(c->chunk_flag); dfree(c->chunk_list); dfree(c->d_counts); dfree(c->partial); dfree(c->scal);
     dfree(c->d_vmax);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -106,7 +113,20 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     A(c->density, B) A(c->active, B) A(c->active_back, B) A(c->label, B) A(c->band, B) A(c->seed, B)
     A(c->tmp_u8, B) A(c->row_index, B + 1)
     A(c->flags, B) A(c->diag, B) A(c->invdiag, B) A(c->rhs, B)
-    A(c->x, B) A(c->r, B) A(c->z, B) A(c->pv[0], B) A(c->pv[1], B) A(c->ap, B)
+    {
+        const int64_t plane = (int64_t)desc->nx * desc->ny;
+        c->pad = ((plane + FLIP_BLOCK + 63) / 64) * 64;
+        double **dp[] = { &c->x, &c->r, &c->z, &c->pv[0], &c->pv[1], &c->ap, &c->cg_diag, &c->cg_inv };
+        for (double **q : dp) {
+            A(*q, B + 2 * c->pad)
+            if (e == hipSuccess) *q += c->pad;
+        }
+        for (int a = 0; a < 3; ++a) {
+            A(c->cg_c[a], B + 2 * c->pad)
+            if (e == hipSuccess) c->cg_c[a] += c->pad;
+        }
+    }
+    A(c->cg_scan, B + 1) A(c->cg_rows, B)
     A(c->chunk_flag, c->n_chunks + 1) A(c->chunk_list, c->n_chunks + 1)
     A(c->d_counts, 8) A(c->partial, 16 * FLIP_MAX_PCG_BLOCKS) A(c->scal, 1) A(c->d_vmax, 3 * FLIP_MAX_PCG_BLOCKS)
 #undef A
@@ -134,6 +154,10 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
         if (nb < 8) nb = 8;
         if (nb > FLIP_MAX_PCG_BLOCKS) nb = FLIP_MAX_PCG_BLOCKS;
         c->pcg_blocks = nb;
+        if (const char *env = getenv("FLIP_PCG_BLOCKS")) { // tuning aid: workgroups of the PCG kernels
+            const int v = atoi(env);
+            if (v >= 8 && v <= FLIP_MAX_PCG_BLOCKS) c->pcg_blocks = (v / 8) * 8;
+        }
     }
     *out = c;
     return 0;

@@ -87,7 +87,16 @@ struct flip_ctx {
     uint8_t *flags = nullptr;
     double *diag = nullptr, *invdiag = nullptr, *rhs = nullptr;
     double *J[6] = {};              // rigid-body rows, dense over the box
+    // Solver arrays carry `pad` zero elements on both sides (pointers are pre-offset), so the stencil
+    // kernels read c +- 1, c +- nx, c +- nx*ny of any cell of the box without a bounds test.
+    int64_t pad = 0;
     double *x = nullptr, *r = nullptr, *z = nullptr, *pv[2] = {}, *ap = nullptr;
+    // CG view of the system: symmetric coupling coefficient toward the low x/y/z neighbour (0 = none),
+    // diagonal and Jacobi inverse; all zero on cells that are not rows of the CG system
+    float *cg_c[3] = {};
+    double *cg_diag = nullptr, *cg_inv = nullptr;
+    int32_t *cg_scan = nullptr;     // [B+1] scan scratch
+    int32_t *cg_rows = nullptr;     // [B] cell ids of the CG rows, ascending; count in d_counts[6]
     int32_t *chunk_flag = nullptr, *chunk_list = nullptr;   // [n_chunks+1]
     int32_t *d_counts = nullptr;    // [8] device counters: 0 rows, 1 active chunks, 2 overdense, 3 outside
     int32_t n_rows = 0, n_active_chunks = 0;

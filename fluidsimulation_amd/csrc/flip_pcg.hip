@@ -32,6 +32,8 @@ struct BuildArgs {
     float *tx, *ty, *tz;
     uint8_t *flags;
     double *diag, *invdiag, *rhs;
+    float *cgx, *cgy, *cgz;   // CG view (see flip_ctx)
+    double *cg_diag, *cg_inv;
     int32_t *chunk_flag;
     // rigid-body coupling (kind 0 only)
     int coupled;
@@ -133,6 +135,13 @@ __global__ void k_build_system(BuildArgs A) {
                     atomicAdd(A.counters + 5, 1);
             }
         }
+        // CG view: rows that take part in the CG iteration; the coupling of two such rows is symmetric
+        const bool cg = (fl & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW;
+        A.cgx[c] = (cg && (fl & 1)) ? (1 - w_lo[0]) * A.scale : 0.f;
+        A.cgy[c] = (cg && (fl & 4)) ? (1 - w_lo[1]) * A.scale : 0.f;
+        A.cgz[c] = (cg && (fl & 16)) ? (1 - w_lo[2]) * A.scale : 0.f;
+        A.cg_diag[c] = cg ? dg : 0.0;
+        A.cg_inv[c] = cg ? inv : 0.0;
         A.flags[c] = fl;
         A.diag[c] = dg;
         A.invdiag[c] = inv;
@@ -153,6 +162,18 @@ __global__ void k_compact_chunks(int n_chunks, const int32_t *__restrict__ flag_
     if (q >= n_chunks) return;
     (void)flag_raw_next;
     if (flag_scan[q + 1] > flag_scan[q]) list[flag_scan[q]] = q;
+}
+
+__global__ void k_mark_cg_rows(long long B, const uint8_t *__restrict__ flags, int32_t *__restrict__ mark) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > B) return;
+    mark[c] = (c < B && (flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW) ? 1 : 0;
+}
+__global__ void k_compact_cg_rows(long long B, const uint8_t *__restrict__ flags, const int32_t *__restrict__ scan,
+                                  int32_t *__restrict__ rows) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    if ((flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW) rows[scan[c]] = (int32_t)c;
 }
 
 extern "C" int flip_set_system_options(flip_ctx *ctx, int drop_null_rows, int eliminate_dependent_rows) {
@@ -188,6 +209,8 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     A.tx = ctx->term[0]; A.ty = ctx->term[1]; A.tz = ctx->term[2];
     A.flags = ctx->flags; A.diag = ctx->diag; A.invdiag = ctx->invdiag; A.rhs = ctx->rhs;
     A.chunk_flag = ctx->chunk_flag;
+    A.cgx = ctx->cg_c[0]; A.cgy = ctx->cg_c[1]; A.cgz = ctx->cg_c[2];
+    A.cg_diag = ctx->cg_diag; A.cg_inv = ctx->cg_inv;
     A.coupled = (kind == 0 && ctx->has_obj) ? 1 : 0;
     A.drop_null = ctx->drop_null_rows ? 1 : 0;
     A.eliminate = ctx->eliminate_dep ? 1 : 0;
@@ -216,6 +239,13 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     k_compact_chunks<<<flip_grid_blocks(ctx->n_chunks), FLIP_BLOCK, 0, st>>>(ctx->n_chunks, ctx->chunk_flag, nullptr, ctx->chunk_list);
     FLIP_LAUNCH_CHECK();
     FLIP_CHECK(hipMemcpyAsync(ctx->d_counts + 1, ctx->chunk_flag + ctx->n_chunks, 4, hipMemcpyDeviceToDevice, st));
+    // compact list of the cells that are rows of the CG system, ascending cell id
+    k_mark_cg_rows<<<flip_grid_blocks(ctx->B + 1), FLIP_BLOCK, 0, st>>>(ctx->B, ctx->flags, ctx->cg_scan);
+    FLIP_LAUNCH_CHECK();
+    if (int rc = flip_exclusive_scan(ctx, ctx->cg_scan, ctx->B + 1)) return rc;
+    k_compact_cg_rows<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, ctx->flags, ctx->cg_scan, ctx->cg_rows);
+    FLIP_LAUNCH_CHECK();
+    FLIP_CHECK(hipMemcpyAsync(ctx->d_counts + 6, ctx->cg_scan + ctx->B, 4, hipMemcpyDeviceToDevice, st));
     ctx->sys_kind = kind;
     ctx->sys_dt = dt;
     ctx->sys_s2 = A.s2;
@@ -270,10 +300,14 @@ struct PcgArgs {
     int nblk;
     double s2;
     const int32_t *chunk_list;
-    const int32_t *n_active; // device scalar
+    const int32_t *n_active; // device scalar: active chunks
+    const int32_t *rows;     // cell ids of the CG rows
+    const int32_t *n_cg;     // device scalar: CG rows
     const uint8_t *flags;
     const float *tx, *ty, *tz;
     const double *diag, *invdiag, *rhs;
+    const float *cgx, *cgy, *cgz;
+    const double *cg_diag, *cg_inv;
     double *x, *r, *z, *p0, *p1, *ap;
     double *partial; // [16][FLIP_MAX_PCG_BLOCKS]
     flip_pcg_scalars *scal;
@@ -313,27 +347,30 @@ __device__ __forceinline__ double d_apply_row(const PcgArgs &A, long long c, uin
     return s;
 }
 
+// The CG kernels walk the compact list of CG rows (ascending cell ids): every lane has a row whatever the
+// shape of the liquid.  Same XCD-aware split as the chunk list: one contiguous run of rows per XCD.
+__device__ __forceinline__ void d_row_range(const PcgArgs &A, long long &lo, long long &hi) {
+    const int per = A.nblk >> 3;
+    const int rank = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const long long n = *A.n_cg;
+    lo = (n * rank) / A.nblk;
+    hi = (n * (rank + 1)) / A.nblk;
+}
+
+// x, z, p0, p1 are zeroed by the host before this kernel (cells off the CG rows must read as zero).
 __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_init(PcgArgs A) {
     __shared__ double scratch[4];
-    int lo, hi;
-    d_chunk_range(A, lo, hi);
+    long long lo, hi;
+    d_row_range(A, lo, hi);
     double rr = 0.0, rz = 0.0;
-    for (int q = lo; q < hi; ++q) {
-        const long long c = (long long)A.chunk_list[q] * FLIP_BLOCK + threadIdx.x;
-        if (c >= A.B) continue;
-        double r = 0.0, z = 0.0;
-        if ((A.flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW) {
-            r = A.rhs[c];
-            z = A.invdiag[c] * r;
-            rr += r * r;
-            rz += r * z;
-        }
+    for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
+        const long long c = A.rows[q];
+        const double r = A.rhs[c];
+        const double z = A.cg_inv[c] * r;
+        rr += r * r;
+        rz += r * z;
         A.r[c] = r;
         A.z[c] = z;
-        A.x[c] = 0.0;
-        A.p0[c] = 0.0;
-        A.p1[c] = 0.0;
-        A.ap[c] = 0.0;
     }
     rr = d_block_sum(rr, scratch);
     rz = d_block_sum(rz, scratch);
@@ -343,6 +380,11 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_init(PcgArgs A) {
     }
 }
 
+// SYM = true: the CG rows couple symmetrically (dependent rows eliminated), so the coefficient toward the
+// high neighbour is the neighbour's low coefficient and every load is unconditional (the arrays are padded
+// and zero off the CG rows): no flags, no branches, all 27 loads of a cell in flight together.
+// SYM = false: CG over all rows of the non-symmetric matrix as the reference runs it (flag-driven).
+template <bool SYM>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_direction(PcgArgs A) {
     __shared__ double scratch[4];
     flip_pcg_scalars *S = A.scal;
@@ -383,23 +425,51 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_direction(PcgArgs A) {
     const double *__restrict__ pold = (it & 1) ? A.p0 : A.p1;
     double *__restrict__ pnew = (it & 1) ? A.p1 : A.p0;
     const double *__restrict__ z = A.z;
-    int lo, hi;
-    d_chunk_range(A, lo, hi);
+    long long lo, hi;
+    d_row_range(A, lo, hi);
     double pap = 0.0;
     double jp[6] = { 0, 0, 0, 0, 0, 0 };
-    for (int q = lo; q < hi; ++q) {
-        const long long c = (long long)A.chunk_list[q] * FLIP_BLOCK + threadIdx.x;
-        if (c >= A.B) continue;
-        const uint8_t fl = A.flags[c];
-        if ((fl & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) != FLIP_FLAG_ROW) continue;
-        const double pc = z[c] + beta * pold[c];
-        const double s = d_apply_row(A, c, fl, pc, [&](long long n) { return z[n] + beta * pold[n]; });
-        pnew[c] = pc;
-        A.ap[c] = s;
-        pap += pc * s;
-        if (A.coupled)
+    if (SYM) {
+        const long long sy = A.sy, sz = A.sz;
+        const float *__restrict__ cx = A.cgx, *__restrict__ cy = A.cgy, *__restrict__ cz = A.cgz;
+        const double *__restrict__ dg = A.cg_diag;
+#pragma unroll 2
+        for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
+            const long long c = A.rows[q];
+            const double z0 = z[c], zxm = z[c - 1], zxp = z[c + 1], zym = z[c - sy], zyp = z[c + sy], zzm = z[c - sz],
+                         zzp = z[c + sz];
+            const double p0 = pold[c], pxm = pold[c - 1], pxp = pold[c + 1], pym = pold[c - sy], pyp = pold[c + sy],
+                         pzm = pold[c - sz], pzp = pold[c + sz];
+            const float axm = cx[c], axp = cx[c + 1], aym = cy[c], ayp = cy[c + sy], azm = cz[c], azp = cz[c + sz];
+            const double d = dg[c];
+            const double pc = z0 + beta * p0;
+            double acc = (double)axm * (zxm + beta * pxm);
+            acc += (double)axp * (zxp + beta * pxp);
+            acc += (double)aym * (zym + beta * pym);
+            acc += (double)ayp * (zyp + beta * pyp);
+            acc += (double)azm * (zzm + beta * pzm);
+            acc += (double)azp * (zzp + beta * pzp);
+            const double s = d * pc - A.s2 * acc;
+            pnew[c] = pc;
+            A.ap[c] = s;
+            pap += pc * s;
+            if (A.coupled)
 #pragma unroll
-            for (int a = 0; a < 6; ++a) jp[a] += A.J[a][c] * pc;
+                for (int a = 0; a < 6; ++a) jp[a] += A.J[a][c] * pc;
+        }
+    } else {
+        for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
+            const long long c = A.rows[q];
+            const uint8_t fl = A.flags[c];
+            const double pc = z[c] + beta * pold[c];
+            const double s = d_apply_row(A, c, fl, pc, [&](long long n) { return z[n] + beta * pold[n]; });
+            pnew[c] = pc;
+            A.ap[c] = s;
+            pap += pc * s;
+            if (A.coupled)
+#pragma unroll
+                for (int a = 0; a < 6; ++a) jp[a] += A.J[a][c] * pc;
+        }
     }
     pap = d_block_sum(pap, scratch);
     if (threadIdx.x == 0) A.partial[2 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = pap;
@@ -430,23 +500,24 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update(PcgArgs A) {
     }
     const double alpha = S->rz[it & 1] / pap;
     const double *__restrict__ p = (it & 1) ? A.p1 : A.p0;
-    int lo, hi;
-    d_chunk_range(A, lo, hi);
+    long long lo, hi;
+    d_row_range(A, lo, hi);
     double rr = 0.0, rz = 0.0;
-    for (int q = lo; q < hi; ++q) {
-        const long long c = (long long)A.chunk_list[q] * FLIP_BLOCK + threadIdx.x;
-        if (c >= A.B) continue;
-        if ((A.flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) != FLIP_FLAG_ROW) continue;
+    const double *__restrict__ inv = A.cg_inv;
+#pragma unroll 2
+    for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
+        const long long c = A.rows[q];
         double apv = A.ap[c];
+        const double pc = p[c], xc = A.x[c], rc = A.r[c], ic = inv[c];
         if (A.coupled) {
             double s = 0.0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) s += A.J[a][c] * gj[a];
             apv += s;
         }
-        A.x[c] += alpha * p[c];
-        const double r = A.r[c] - alpha * apv;
-        const double zz = A.invdiag[c] * r;
+        A.x[c] = xc + alpha * pc;
+        const double r = rc - alpha * apv;
+        const double zz = ic * r;
         A.r[c] = r;
         A.z[c] = zz;
         rr += r * r;
@@ -485,9 +556,13 @@ static void fill_pcg_args(flip_ctx *ctx, PcgArgs &A) {
     A.s2 = ctx->sys_s2;
     A.chunk_list = ctx->chunk_list;
     A.n_active = ctx->d_counts + 1;
+    A.rows = ctx->cg_rows;
+    A.n_cg = ctx->d_counts + 6;
     A.flags = ctx->flags;
     A.tx = ctx->term[0]; A.ty = ctx->term[1]; A.tz = ctx->term[2];
     A.diag = ctx->diag; A.invdiag = ctx->invdiag; A.rhs = ctx->rhs;
+    A.cgx = ctx->cg_c[0]; A.cgy = ctx->cg_c[1]; A.cgz = ctx->cg_c[2];
+    A.cg_diag = ctx->cg_diag; A.cg_inv = ctx->cg_inv;
     A.x = ctx->x; A.r = ctx->r; A.z = ctx->z; A.p0 = ctx->pv[0]; A.p1 = ctx->pv[1]; A.ap = ctx->ap;
     A.partial = ctx->partial;
     A.scal = ctx->scal;
@@ -511,7 +586,11 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
     h.tol2 = tol * tol;
     h.max_iter = max_iter;
     FLIP_CHECK(hipMemcpyAsync(ctx->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
+    // cells off the CG rows must read as zero in x and in the vectors the stencil reads at neighbours
     FLIP_CHECK(hipMemsetAsync(ctx->x, 0, (size_t)ctx->B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->z, 0, (size_t)ctx->B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->pv[0], 0, (size_t)ctx->B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->pv[1], 0, (size_t)ctx->B * 8, st));
 
     PcgArgs A;
     fill_pcg_args(ctx, A);
@@ -527,6 +606,7 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
     FLIP_LAUNCH_CHECK();
 
     const int batch = 32;
+    const bool sym = ctx->sys_eliminated; // dependent rows eliminated -> symmetric CG system
     int launched = 0, n_prof = 0;
     int32_t done = 0;
     // one extra direction launch decides convergence after the last update
@@ -534,7 +614,8 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
         for (int b = 0; b < batch; ++b) {
             const bool prof = ctx->profiling && n_prof < 64;
             if (prof) FLIP_CHECK(hipEventRecord(ctx->events[2 + 2 * n_prof], st));
-            k_pcg_direction<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+            if (sym) k_pcg_direction<true><<<nblk, FLIP_BLOCK, 0, st>>>(A);
+            else k_pcg_direction<false><<<nblk, FLIP_BLOCK, 0, st>>>(A);
             if (prof) { FLIP_CHECK(hipEventRecord(ctx->events[3 + 2 * n_prof], st)); ++n_prof; }
             k_pcg_update<<<nblk, FLIP_BLOCK, 0, st>>>(A);
         }
@@ -549,8 +630,8 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
     }
     FLIP_CHECK(hipEventRecord(ctx->events[1], st));
     FLIP_CHECK(hipMemcpyAsync(&h, ctx->scal, sizeof h, hipMemcpyDeviceToHost, st));
-    int32_t counts[6] = { 0, 0, 0, 0, 0, 0 };
-    FLIP_CHECK(hipMemcpyAsync(counts, ctx->d_counts, 24, hipMemcpyDeviceToHost, st));
+    int32_t counts[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    FLIP_CHECK(hipMemcpyAsync(counts, ctx->d_counts, 32, hipMemcpyDeviceToHost, st));
     FLIP_CHECK(hipStreamSynchronize(st));
     ctx->n_active_chunks = counts[1];
     if (info) {
@@ -560,6 +641,7 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
         info->rows = counts[0];
         info->active_chunks = counts[1];
         info->dependent_rows = counts[4];
+        info->cg_rows = counts[6];
         info->rhs_norm_2 = sqrt(h.rhs_norm2);
         info->rel_residual_2 = h.rhs_norm2 > 0 ? sqrt(h.rr / h.rhs_norm2) : 0.0;
         float ms = 0.f;

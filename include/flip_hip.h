@@ -95,6 +95,7 @@ typedef struct flip_pcg_info {
     int32_t converged;      /* 1 when |r|^2 < tol^2 |b|^2 was reached                      */
     int32_t iterations;     /* number of operator applications                             */
     int32_t rows;           /* system size                                                 */
+    int32_t cg_rows;        /* rows in the CG iteration (rows - dependent_rows)            */
     int32_t active_chunks;  /* 256-cell chunks swept per kernel                            */
     double rel_residual_2;  /* sqrt(|r|^2 / |b|^2), r the recurrence residual (as Eigen)   */
     double rhs_norm_2;      /* |b|                                                         */
@@ -102,6 +103,7 @@ typedef struct flip_pcg_info {
     double spmv_seconds;    /* device time spent in the operator kernel, when profiled     */
     int32_t spmv_launches;  /* launches covered by spmv_seconds                            */
     int32_t dependent_rows; /* rows solved by substitution after CG (see flip_set_system_options) */
+    int32_t reserved;
 } flip_pcg_info;
 
 /* ---- context ---------------------------------------------------------------------------- */

@@ -39,7 +39,9 @@ def test_field_enum_matches_header():
 
 def test_struct_sizes_match_the_c_layout():
     assert ctypes.sizeof(binding.GridDesc) == 6 * 4 + 4 * 4
-    assert ctypes.sizeof(binding.PcgInfo) == 4 * 4 + 4 * 8 + 2 * 4
+    # 5 ints (+4 pad), 4 doubles, 3 ints (+4 pad)
+    assert ctypes.sizeof(binding.PcgInfo) == 24 + 32 + 16
+    assert binding.PcgInfo.rel_residual_2.offset == 24 and binding.PcgInfo.spmv_launches.offset == 56
 
 
 def test_create_fails_loudly_without_a_device():
