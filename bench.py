@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--tol", type=float, default=1e-15)
     ap.add_argument("--max-iter", type=int, default=20000)
+    ap.add_argument("--precond", default=os.environ.get("FLIP_BENCH_PRECOND", "jacobi"), choices=["jacobi", "mg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=40, help="CG iterations per solve timed on the CPU")
     return ap.parse_args()
@@ -131,7 +132,9 @@ def main():
     sc = make_scene(args)
     ctx = FlipContext(sc.desc(), device=local)
     ctx.upload_scene(sc)
-    step = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter)
+    from fluidsimulation_amd import PRECOND_JACOBI, PRECOND_MULTIGRID
+    step = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter,
+                       precond=PRECOND_MULTIGRID if args.precond == "mg" else PRECOND_JACOBI)
 
     def barrier():
         ctx.synchronize()
@@ -178,7 +181,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.scene} {args.n}^3, {args.ppc} particles/cell, density projection on, "
-                                   f"Jacobi CG tol {args.tol:g}",
+                                   f"{args.precond} PCG tol {args.tol:g}",
                        "cells": sc.n_cells, "particles": int(sc.pos.shape[0]), "rows": rows,
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
             "pcg": {"iterations_per_step": iters / args.steps, "seconds_per_step": pcg_s / args.steps,

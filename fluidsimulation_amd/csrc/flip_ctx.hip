@@ -52,6 +52,7 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_particles(c);
+    flip_mg_free(c);
     dfree(c->cell_start); dfree(c->cell_fill); dfree(c->scan_tmp);
     dfree(c->phi_fluid); dfree(c->phi_solid); dfree(c->phi_obj);
     for (int b = 0; b < 4; ++b)

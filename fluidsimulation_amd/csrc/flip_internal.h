@@ -34,6 +34,16 @@ struct flip_pcg_scalars {
     int32_t max_iter;
 };
 
+// One coarse level of the multigrid preconditioner (flip_mg.hip): dense zero-padded arrays over the
+// coarsened box plus the compact list of its rows.
+struct flip_mg_level {
+    int nx = 0, ny = 0, nz = 0;
+    int64_t B = 0, pad = 0;
+    double *cx = nullptr, *cy = nullptr, *cz = nullptr, *diag = nullptr, *inv = nullptr;
+    double *x = nullptr, *b = nullptr, *t = nullptr;
+    int32_t *rows = nullptr, *scan = nullptr, *n_rows = nullptr;
+};
+
 struct flip_ctx {
     flip_grid_desc g;
     int64_t B = 0;       // cells in the box
@@ -106,7 +116,12 @@ struct flip_ctx {
     double *d_vmax = nullptr;       // [3*FLIP_MAX_PCG_BLOCKS]
     bool profiling = false;
     std::vector<hipEvent_t> events;
+    std::vector<flip_mg_level> mg;  // coarse levels, finest first
 };
+
+int flip_mg_setup(flip_ctx *ctx);   // coarse operators of the assembled system
+int flip_mg_vcycle(flip_ctx *ctx);  // z = M^-1 r and the r.z partials
+void flip_mg_free(flip_ctx *ctx);
 
 int flip_fail(flip_ctx *ctx, const char *what, const char *file, int line);
 int flip_fail_hip(flip_ctx *ctx, hipError_t e, const char *what, const char *file, int line);

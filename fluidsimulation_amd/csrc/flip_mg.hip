@@ -1,0 +1,354 @@
+// flip_mg.hip -- geometric multigrid V-cycle used as the CG preconditioner (FLIP_PRECOND_MULTIGRID).
+//
+// It replaces the sequential MIC(0) factorisation and triangular solves of headers/pcgsolver/pcg_solver.h
+// (:80-214) with a preconditioner whose every step is data parallel: the reference has no counterpart.
+//
+//   hierarchy   : cell-centred, 2x2x2 coarsening of the dense box; level 0 is the CG view of the assembled
+//                 system (symmetric couplings of the CG rows).  Coarse operator = 1/2 * P^T A P with P the
+//                 piecewise-constant prolongation: the coupling of two coarse cells is half the sum of the
+//                 four fine couplings across their common face, which is also what re-discretising the
+//                 finite-volume operator on the coarse grid gives (face area x4, distance x2).
+//   smoother    : damped Jacobi, two sweeps before and two after the coarse correction (same weight, so the
+//                 V-cycle is a symmetric operator, as CG requires); the first sweep starts from zero.
+//   transfer    : restriction = sum of the eight child residuals (the equations are volume integrals),
+//                 prolongation = injection of the parent value.
+//   coarsest    : a fixed even number of damped-Jacobi sweeps by one workgroup.
+// Every level keeps dense, zero-padded arrays and a compact list of its rows, like level 0.
+#include "flip_internal.h"
+
+#define MG_OMEGA 0.8
+#define MG_COARSEST_CELLS 4096   // a level with at most this many cells is solved by one workgroup
+#define MG_COARSEST_SWEEPS 40
+
+template <class CT>
+struct MgDev {
+    long long B, sy, sz;
+    int nx, ny, nz;
+    const CT *cx, *cy, *cz;   // coupling toward the low x/y/z neighbour (0 = none)
+    double scale;             // couplings are multiplied by this (dx^2 of the divergence system on level 0)
+    const double *diag, *inv;
+    double *x, *b, *t;
+    const int32_t *rows;
+    const int32_t *n_rows;
+};
+
+template <class CT>
+__device__ __forceinline__ double d_mg_apply(const MgDev<CT> &L, long long c, const double *__restrict__ v) {
+    double acc = (double)L.cx[c] * v[c - 1];
+    acc += (double)L.cx[c + 1] * v[c + 1];
+    acc += (double)L.cy[c] * v[c - L.sy];
+    acc += (double)L.cy[c + L.sy] * v[c + L.sy];
+    acc += (double)L.cz[c] * v[c - L.sz];
+    acc += (double)L.cz[c + L.sz] * v[c + L.sz];
+    return L.diag[c] * v[c] - L.scale * acc;
+}
+
+// out = omega D^-1 b   (first sweep from a zero guess)
+template <class CT>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth_first(MgDev<CT> L, const int32_t *done, double *__restrict__ out) {
+    if (done && *done) return;
+    const long long n = *L.n_rows;
+    for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
+        const long long c = L.rows[q];
+        out[c] = MG_OMEGA * L.inv[c] * L.b[c];
+    }
+}
+
+// out = in + omega D^-1 (b - A in); RZ: also the per-workgroup partial of b.out into `partial`
+template <class CT, bool RZ>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, const int32_t *done, const double *__restrict__ in,
+                                                         double *__restrict__ out, double *__restrict__ partial) {
+    __shared__ double scratch[4];
+    if (done && *done) return;
+    const long long n = *L.n_rows;
+    double acc = 0.0;
+    if (RZ) {
+        // same split of the row list as the CG kernels, so the partial layout matches their reduction
+        const int per = gridDim.x >> 3;
+        const int rank = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        const long long lo = (n * rank) / gridDim.x, hi = (n * (rank + 1)) / gridDim.x;
+#pragma unroll 2
+        for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
+            const long long c = L.rows[q];
+            const double b = L.b[c];
+            const double v = in[c] + MG_OMEGA * L.inv[c] * (b - d_mg_apply(L, c, in));
+            out[c] = v;
+            acc += b * v;
+        }
+        acc = d_block_sum(acc, scratch);
+        if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+    } else {
+#pragma unroll 2
+        for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
+            const long long c = L.rows[q];
+            out[c] = in[c] + MG_OMEGA * L.inv[c] * (L.b[c] - d_mg_apply(L, c, in));
+        }
+    }
+}
+
+// coarse b = sum over the eight children of (b - A v) on the fine level; coarse x and t are not touched
+template <class CT>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<double> C, const int32_t *done,
+                                                           const double *__restrict__ v) {
+    if (done && *done) return;
+    const long long n = *C.n_rows;
+    for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
+        const long long cc = C.rows[q];
+        const int I = (int)(cc % C.nx);
+        const long long tq = cc / C.nx;
+        const int J = (int)(tq % C.ny), K = (int)(tq / C.ny);
+        double s = 0.0;
+#pragma unroll
+        for (int dk = 0; dk < 2; ++dk)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+                for (int di = 0; di < 2; ++di) {
+                    const int i = 2 * I + di, j = 2 * J + dj, k = 2 * K + dk;
+                    if (i < F.nx && j < F.ny && k < F.nz) {
+                        const long long c = (long long)i + F.sy * j + F.sz * k;
+                        if (F.inv[c] != 0.0) s += F.b[c] - d_mg_apply(F, c, v);
+                    }
+                }
+        C.b[cc] = s;
+    }
+}
+
+// fine v += coarse x of the parent
+template <class CT>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_prolong(MgDev<CT> F, MgDev<double> C, const int32_t *done,
+                                                          double *__restrict__ v) {
+    if (done && *done) return;
+    const long long n = *F.n_rows;
+    for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
+        const long long c = F.rows[q];
+        const int i = (int)(c % F.nx);
+        const long long tq = c / F.nx;
+        const int j = (int)(tq % F.ny), k = (int)(tq / F.ny);
+        const long long cc = (long long)(i >> 1) + C.sy * (j >> 1) + C.sz * (k >> 1);
+        v[c] += C.x[cc];
+    }
+}
+
+// Coarsest level: one workgroup, fixed even number of damped-Jacobi sweeps from zero, result in x.
+__global__ void __launch_bounds__(1024) k_mg_coarsest(MgDev<double> L, const int32_t *done) {
+    if (done && *done) return;
+    const long long n = *L.n_rows;
+    for (long long q = threadIdx.x; q < n; q += blockDim.x) {
+        const long long c = L.rows[q];
+        L.x[c] = MG_OMEGA * L.inv[c] * L.b[c];
+    }
+    __syncthreads();
+    double *a = L.x, *b2 = L.t;
+    for (int s = 1; s < MG_COARSEST_SWEEPS; ++s) {
+        for (long long q = threadIdx.x; q < n; q += blockDim.x) {
+            const long long c = L.rows[q];
+            b2[c] = a[c] + MG_OMEGA * L.inv[c] * (L.b[c] - d_mg_apply(L, c, a));
+        }
+        __syncthreads();
+        double *tmp = a; a = b2; b2 = tmp;
+    }
+    // MG_COARSEST_SWEEPS is even: sweeps 1..S-1 make an odd number of swaps, so the result sits in t
+    for (long long q = threadIdx.x; q < n; q += blockDim.x) {
+        const long long c = L.rows[q];
+        L.x[c] = a[c];
+    }
+}
+
+// Galerkin coarsening with piecewise-constant transfer, scaled by 1/2 (see the header comment).
+template <class CT>
+__global__ void k_mg_coarsen(MgDev<CT> F, int cnx, int cny, int cnz, long long csy, long long csz, double *__restrict__ cx,
+                             double *__restrict__ cy, double *__restrict__ cz, double *__restrict__ diag,
+                             double *__restrict__ inv, int32_t *__restrict__ mark) {
+    const long long cB = (long long)cnx * cny * cnz;
+    const long long cc = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cc > cB) return;
+    if (cc == cB) { mark[cc] = 0; return; }
+    const int I = (int)(cc % cnx);
+    const long long tq = cc / cnx;
+    const int J = (int)(tq % cny), K = (int)(tq / cny);
+    double sx = 0, sy_ = 0, sz_ = 0, sd = 0, internal = 0;
+    for (int dk = 0; dk < 2; ++dk)
+        for (int dj = 0; dj < 2; ++dj)
+            for (int di = 0; di < 2; ++di) {
+                const int i = 2 * I + di, j = 2 * J + dj, k = 2 * K + dk;
+                if (i >= F.nx || j >= F.ny || k >= F.nz) continue;
+                const long long c = (long long)i + F.sy * j + F.sz * k;
+                sd += F.diag[c];
+                const double ax = F.scale * (double)F.cx[c], ay = F.scale * (double)F.cy[c], az = F.scale * (double)F.cz[c];
+                if (di == 0) sx += ax; else internal += ax;   // low face of the coarse cell / face between two children
+                if (dj == 0) sy_ += ay; else internal += ay;
+                if (dk == 0) sz_ += az; else internal += az;
+            }
+    const double d = 0.5 * (sd - 2.0 * internal);
+    const bool row = d > 0.0;
+    cx[cc] = row ? 0.5 * sx : 0.0;
+    cy[cc] = row ? 0.5 * sy_ : 0.0;
+    cz[cc] = row ? 0.5 * sz_ : 0.0;
+    diag[cc] = row ? d : 0.0;
+    inv[cc] = row ? 1.0 / d : 0.0;
+    mark[cc] = row ? 1 : 0;
+}
+// a coupling must vanish when the neighbour on its low side is not a row (its own arrays are zero there,
+// but the coefficient is stored with the high cell)
+__global__ void k_mg_prune(int cnx, int cny, int cnz, long long csy, long long csz, const double *__restrict__ inv,
+                           double *__restrict__ cx, double *__restrict__ cy, double *__restrict__ cz) {
+    const long long cB = (long long)cnx * cny * cnz;
+    const long long cc = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cc >= cB) return;
+    const int I = (int)(cc % cnx);
+    const long long tq = cc / cnx;
+    const int J = (int)(tq % cny), K = (int)(tq / cny);
+    if (I == 0 || inv[cc - 1] == 0.0) cx[cc] = 0.0;
+    if (J == 0 || inv[cc - csy] == 0.0) cy[cc] = 0.0;
+    if (K == 0 || inv[cc - csz] == 0.0) cz[cc] = 0.0;
+}
+__global__ void k_mg_compact(long long B, const int32_t *__restrict__ scan, int32_t *__restrict__ rows) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    if (scan[c + 1] > scan[c]) rows[scan[c]] = (int32_t)c;
+}
+
+// ---------------------------------------------------------------------------------------------
+
+static hipError_t mg_alloc_padded(double **p, int64_t n, int64_t pad) {
+    hipError_t e = hipMalloc((void **)p, (size_t)(n + 2 * pad) * sizeof(double));
+    if (e != hipSuccess) return e;
+    e = hipMemset(*p, 0, (size_t)(n + 2 * pad) * sizeof(double));
+    *p += pad;
+    return e;
+}
+
+void flip_mg_free(flip_ctx *ctx) {
+    for (flip_mg_level &L : ctx->mg) {
+        double **dp[] = { &L.cx, &L.cy, &L.cz, &L.diag, &L.inv, &L.x, &L.b, &L.t };
+        for (double **q : dp)
+            if (*q) { (void)hipFree(*q - L.pad); *q = nullptr; }
+        if (L.rows) (void)hipFree(L.rows);
+        if (L.scan) (void)hipFree(L.scan);
+        if (L.n_rows) (void)hipFree(L.n_rows);
+    }
+    ctx->mg.clear();
+}
+
+// Allocates the level arrays once per context (sizes depend on the box only).
+static int mg_ensure_levels(flip_ctx *ctx) {
+    if (!ctx->mg.empty()) return 0;
+    int nx = ctx->g.nx, ny = ctx->g.ny, nz = ctx->g.nz;
+    for (;;) {
+        const int64_t fineB = (int64_t)nx * ny * nz;
+        if (fineB <= MG_COARSEST_CELLS || (nx <= 2 && ny <= 2 && nz <= 2)) break;
+        nx = (nx + 1) / 2; ny = (ny + 1) / 2; nz = (nz + 1) / 2;
+        flip_mg_level L;
+        L.nx = nx; L.ny = ny; L.nz = nz;
+        L.B = (int64_t)nx * ny * nz;
+        L.pad = (((int64_t)nx * ny + FLIP_BLOCK + 63) / 64) * 64;
+        hipError_t e = hipSuccess;
+        double **dp[] = { &L.cx, &L.cy, &L.cz, &L.diag, &L.inv, &L.x, &L.b, &L.t };
+        for (double **q : dp)
+            if (e == hipSuccess) e = mg_alloc_padded(q, L.B, L.pad);
+        if (e == hipSuccess) e = hipMalloc((void **)&L.rows, (size_t)L.B * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&L.scan, (size_t)(L.B + 1) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&L.n_rows, 4);
+        ctx->mg.push_back(L);
+        if (e != hipSuccess) {
+            flip_mg_free(ctx);
+            return flip_fail_hip(ctx, e, "hipMalloc of the multigrid levels", __FILE__, __LINE__);
+        }
+    }
+    return 0;
+}
+
+static MgDev<float> mg_level0(flip_ctx *ctx) {
+    MgDev<float> L;
+    L.B = ctx->B; L.sy = ctx->g.nx; L.sz = (long long)ctx->g.nx * ctx->g.ny;
+    L.nx = ctx->g.nx; L.ny = ctx->g.ny; L.nz = ctx->g.nz;
+    L.cx = ctx->cg_c[0]; L.cy = ctx->cg_c[1]; L.cz = ctx->cg_c[2];
+    L.scale = ctx->sys_s2;
+    L.diag = ctx->cg_diag; L.inv = ctx->cg_inv;
+    L.x = ctx->z; L.b = ctx->r; L.t = ctx->ap;   // z = M^-1 r; Ap is free between the update and direction kernels
+    L.rows = ctx->cg_rows; L.n_rows = ctx->d_counts + 6;
+    return L;
+}
+static MgDev<double> mg_level(const flip_mg_level &S) {
+    MgDev<double> L;
+    L.B = S.B; L.sy = S.nx; L.sz = (long long)S.nx * S.ny;
+    L.nx = S.nx; L.ny = S.ny; L.nz = S.nz;
+    L.cx = S.cx; L.cy = S.cy; L.cz = S.cz;
+    L.scale = 1.0;
+    L.diag = S.diag; L.inv = S.inv;
+    L.x = S.x; L.b = S.b; L.t = S.t;
+    L.rows = S.rows; L.n_rows = S.n_rows;
+    return L;
+}
+
+template <class CT>
+static int mg_coarsen_into(flip_ctx *ctx, const MgDev<CT> &F, flip_mg_level &S) {
+    hipStream_t st = ctx->stream;
+    const long long csy = S.nx, csz = (long long)S.nx * S.ny;
+    k_mg_coarsen<CT><<<flip_grid_blocks(S.B + 1), FLIP_BLOCK, 0, st>>>(F, S.nx, S.ny, S.nz, csy, csz, S.cx, S.cy, S.cz, S.diag,
+                                                                      S.inv, S.scan);
+    FLIP_LAUNCH_CHECK();
+    k_mg_prune<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.nx, S.ny, S.nz, csy, csz, S.inv, S.cx, S.cy, S.cz);
+    FLIP_LAUNCH_CHECK();
+    if (int rc = flip_exclusive_scan(ctx, S.scan, S.B + 1)) return rc;
+    k_mg_compact<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.B, S.scan, S.rows);
+    FLIP_LAUNCH_CHECK();
+    FLIP_CHECK(hipMemcpyAsync(S.n_rows, S.scan + S.B, 4, hipMemcpyDeviceToDevice, st));
+    // vectors of a previous solve may be non-zero on cells that are no longer rows
+    FLIP_CHECK(hipMemsetAsync(S.x, 0, (size_t)S.B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(S.t, 0, (size_t)S.B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(S.b, 0, (size_t)S.B * 8, st));
+    return 0;
+}
+
+// Builds the coarse operators for the system currently assembled (called once per solve).
+int flip_mg_setup(flip_ctx *ctx) {
+    if (int rc = mg_ensure_levels(ctx)) return rc;
+    FLIP_REQUIRE(!ctx->mg.empty(), "multigrid: the box is too small to coarsen (use the Jacobi preconditioner)");
+    if (int rc = mg_coarsen_into(ctx, mg_level0(ctx), ctx->mg[0])) return rc;
+    for (size_t l = 1; l < ctx->mg.size(); ++l)
+        if (int rc = mg_coarsen_into(ctx, mg_level(ctx->mg[l - 1]), ctx->mg[l])) return rc;
+    return 0;
+}
+
+static int mg_blocks(const flip_ctx *ctx, int64_t B) {
+    int64_t nb = (B + FLIP_BLOCK - 1) / FLIP_BLOCK;
+    if (nb > ctx->pcg_blocks) nb = ctx->pcg_blocks;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+// One V-cycle: z = M^-1 r on level 0, and the partials of r.z in slot 1 for the next direction kernel.
+int flip_mg_vcycle(flip_ctx *ctx) {
+    hipStream_t st = ctx->stream;
+    const int32_t *done = &ctx->scal->done;
+    const int nblk = ctx->pcg_blocks;
+    const size_t nl = ctx->mg.size();
+    MgDev<float> L0 = mg_level0(ctx);
+    // ---- down ----
+    k_mg_smooth_first<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.t);
+    k_mg_smooth<float, false><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.t, L0.x, nullptr);
+    k_mg_restrict<float><<<mg_blocks(ctx, ctx->mg[0].B), FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x);
+    for (size_t l = 0; l + 1 < nl; ++l) {
+        MgDev<double> F = mg_level(ctx->mg[l]);
+        const int nb = mg_blocks(ctx, ctx->mg[l].B);
+        k_mg_smooth_first<double><<<nb, FLIP_BLOCK, 0, st>>>(F, done, F.t);
+        k_mg_smooth<double, false><<<nb, FLIP_BLOCK, 0, st>>>(F, done, F.t, F.x, nullptr);
+        k_mg_restrict<double><<<mg_blocks(ctx, ctx->mg[l + 1].B), FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x);
+    }
+    // ---- coarsest ----
+    k_mg_coarsest<<<1, 1024, 0, st>>>(mg_level(ctx->mg[nl - 1]), done);
+    // ---- up ----
+    for (size_t l = nl - 1; l-- > 0;) {
+        MgDev<double> F = mg_level(ctx->mg[l]);
+        const int nb = mg_blocks(ctx, ctx->mg[l].B);
+        k_mg_prolong<double><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x);
+        k_mg_smooth<double, false><<<nb, FLIP_BLOCK, 0, st>>>(F, done, F.x, F.t, nullptr);
+        k_mg_smooth<double, false><<<nb, FLIP_BLOCK, 0, st>>>(F, done, F.t, F.x, nullptr);
+    }
+    k_mg_prolong<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x);
+    k_mg_smooth<float, false><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.x, L0.t, nullptr);
+    k_mg_smooth<float, true><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.t, L0.x, ctx->partial + 1 * FLIP_MAX_PCG_BLOCKS);
+    FLIP_LAUNCH_CHECK();
+    return 0;
+}

@@ -574,7 +574,11 @@ static void fill_pcg_args(flip_ctx *ctx, PcgArgs &A) {
 extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int precond, flip_pcg_info *info) {
     FLIP_REQUIRE(ctx, "null context");
     FLIP_REQUIRE(ctx->sys_kind >= 0, "flip_pcg_solve: call flip_build_system first");
-    FLIP_REQUIRE(precond == FLIP_PRECOND_JACOBI, "flip_pcg_solve: only the Jacobi preconditioner is built in this version");
+    FLIP_REQUIRE(precond == FLIP_PRECOND_JACOBI || precond == FLIP_PRECOND_MULTIGRID, "flip_pcg_solve: unknown preconditioner");
+    // the V-cycle is a symmetric operator for the symmetric CG system; a box too small to coarsen keeps Jacobi
+    bool use_mg = precond == FLIP_PRECOND_MULTIGRID && ctx->B > 4096;
+    FLIP_REQUIRE(!use_mg || ctx->sys_eliminated,
+                 "flip_pcg_solve: the multigrid preconditioner needs eliminate_dependent_rows = 1 (symmetric system)");
     FLIP_REQUIRE(tol > 0.0, "flip_pcg_solve: tol must be positive");
     FLIP_REQUIRE(ctx->pcg_blocks % 8 == 0 && ctx->pcg_blocks <= FLIP_MAX_PCG_BLOCKS, "flip_pcg_solve: bad grid size");
     FLIP_CHECK(hipSetDevice(ctx->device));
@@ -591,6 +595,10 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
     FLIP_CHECK(hipMemsetAsync(ctx->z, 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->pv[0], 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->pv[1], 0, (size_t)ctx->B * 8, st));
+    if (use_mg) {
+        FLIP_CHECK(hipMemsetAsync(ctx->ap, 0, (size_t)ctx->B * 8, st)); // V-cycle scratch on level 0
+        if (int rc = flip_mg_setup(ctx)) return rc;
+    }
 
     PcgArgs A;
     fill_pcg_args(ctx, A);
@@ -604,8 +612,10 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
     FLIP_CHECK(hipEventRecord(ctx->events[0], st));
     k_pcg_init<<<nblk, FLIP_BLOCK, 0, st>>>(A);
     FLIP_LAUNCH_CHECK();
+    if (use_mg)
+        if (int rc = flip_mg_vcycle(ctx)) return rc;
 
-    const int batch = 32;
+    const int batch = use_mg ? 8 : 32;
     const bool sym = ctx->sys_eliminated; // dependent rows eliminated -> symmetric CG system
     int launched = 0, n_prof = 0;
     int32_t done = 0;
@@ -618,6 +628,8 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
             else k_pcg_direction<false><<<nblk, FLIP_BLOCK, 0, st>>>(A);
             if (prof) { FLIP_CHECK(hipEventRecord(ctx->events[3 + 2 * n_prof], st)); ++n_prof; }
             k_pcg_update<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+            if (use_mg)
+                if (int rc = flip_mg_vcycle(ctx)) return rc;
         }
         FLIP_LAUNCH_CHECK();
         launched += batch;

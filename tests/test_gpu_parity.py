@@ -369,6 +369,42 @@ def test_crowded_cell_sort_is_stable():
             assert np.array_equal(g_id, cell_id) and np.array_equal(g_start, cell_start) and np.array_equal(g_perm, perm)
 
 
+@pytest.mark.parametrize("n", [32, 48])
+def test_multigrid_preconditioner_reaches_the_same_solution(n):
+    """FLIP_PRECOND_MULTIGRID replaces the sequential MIC(0) of headers/pcgsolver; it has no counterpart in the
+    reference, so the check is: same tolerance reached, same pressure as the as-run Jacobi CG (and as the
+    oracle's CG), both solves, first and second substep, in far fewer iterations."""
+    from fluidsimulation_amd import FlipSubstep, PRECOND_JACOBI, PRECOND_MULTIGRID
+    sc = scenes.dam_break(n, ppc=4, seed=6)
+    rng = np.random.default_rng(12)
+    sc.vel = rng.normal(0, 0.3, sc.pos.shape)
+    o = Oracle(sc.desc(), threads=8)
+    ref = o.substep(fresh_state(sc, o), 0.005)
+    lab = ref["label"].astype(bool)
+    results = {}
+    for precond in (PRECOND_JACOBI, PRECOND_MULTIGRID):
+        with FlipContext(sc.desc()) as ctx:
+            ctx.upload_scene(sc)
+            step = FlipSubstep(ctx, precond=precond)
+            infos = [step.step(0.005)]
+            p_den = ctx.download("pressure")[lab]
+            pos, vel = ctx.download_particles()
+            infos.append(step.step(0.005))       # second substep: stale weights, dependent rows
+            pos2, vel2 = ctx.download_particles()
+            results[precond] = (infos, p_den, pos, vel, pos2, vel2)
+    ja, mg = results[PRECOND_JACOBI], results[PRECOND_MULTIGRID]
+    for infos in (ja[0], mg[0]):
+        for info in infos:
+            for k in ("divergence", "density"):
+                assert info[k]["converged"] == 1 and info[k]["rel_residual_2"] < RES_TOL
+    assert rel_linf(mg[1], ref["p_den"]) < 1e-8 and rel_linf(ja[1], ref["p_den"]) < 1e-8
+    assert np.abs(mg[2] - ref["new_pos"]).max() < POS_ATOL and rel_linf(mg[3], ref["new_vel"]) < VEL_RTOL
+    assert np.abs(mg[4] - ja[4]).max() < POS_ATOL and rel_linf(mg[5], ja[5]) < VEL_RTOL
+    for s in (0, 1):
+        for k in ("divergence", "density"):
+            assert mg[0][s][k]["iterations"] * 3 < ja[0][s][k]["iterations"], (s, k, mg[0][s][k], ja[0][s][k])
+
+
 @pytest.mark.parametrize("n,ppc", [(32, 8)])
 def test_larger_scene_properties(n, ppc):
     """Size-independent checks at a size the oracle still finishes in seconds: sortedness of the binning,
