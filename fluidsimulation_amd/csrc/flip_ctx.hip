@@ -44,6 +44,7 @@ static void free_particles(flip_ctx *c) {
     dfree(c->slot_src);
     dfree(c->slot_key);
     dfree(c->stage);
+    dfree(c->prec);
     c->cap = 0;
 }
 
@@ -271,6 +272,7 @@ static int ensure_particle_capacity(flip_ctx *ctx, int64_t n) {
     if (e == hipSuccess) e = dalloc(&ctx->slot_src, cap);
     if (e == hipSuccess) e = dalloc(&ctx->slot_key, cap);
     if (e == hipSuccess) e = dalloc(&ctx->stage, cap * 6);
+    if (e == hipSuccess) e = dalloc(&ctx->prec, cap);
     if (e != hipSuccess) return flip_fail_hip(ctx, e, "hipMalloc of the particle arrays", __FILE__, __LINE__);
     ctx->cap = cap;
     return 0;
@@ -285,6 +287,7 @@ extern "C" int flip_particles_upload(flip_ctx *ctx, int64_t n, const double *pos
     ctx->n = n;
     ctx->cur = 0;
     ctx->binned = false;
+    ctx->prec_valid = false;
     if (n == 0) return 0;
     FLIP_CHECK(hipMemcpyAsync(ctx->stage, pos, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
     FLIP_CHECK(hipMemcpyAsync(ctx->stage + 3 * ctx->cap, vel, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));

@@ -34,6 +34,13 @@ struct flip_pcg_scalars {
     int32_t max_iter;
 };
 
+// Packed particle record read by the gather kernels (P2G, density): one 64-byte line per particle instead of
+// one line in each of seven SoA arrays, because neighbouring lanes walk different particle ranges.
+struct alignas(64) flip_prec {
+    double x, y, z, vx, vy, vz;
+    float mass, pad0, pad1, pad2;
+};
+
 // One coarse level of the multigrid preconditioner (flip_mg.hip): dense zero-padded arrays over the
 // coarsened box plus the compact list of its rows.
 struct flip_mg_level {
@@ -66,6 +73,8 @@ struct flip_ctx {
     int32_t *scan_tmp = nullptr;    // block sums of the scan
     int64_t scan_tmp_len = 0;
     double *stage = nullptr;        // [cap*3] upload/download staging (AoS)
+    flip_prec *prec = nullptr;      // [cap] packed copy of the sorted particles for the gather kernels
+    bool prec_valid = false;
     bool binned = false;
     int64_t n_outside = 0;
 

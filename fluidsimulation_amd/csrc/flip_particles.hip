@@ -88,15 +88,29 @@ struct ParticlePtrs {
     int32_t *pid;
 };
 __global__ void k_reorder(long long n, const int32_t *__restrict__ slot_src, const int32_t *__restrict__ slot_key,
-                          const int32_t *__restrict__ cell_id_old, ParticlePtrs src, ParticlePtrs dst) {
+                          ParticlePtrs src, ParticlePtrs dst, flip_prec *__restrict__ prec) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const int32_t o = slot_src[s];
+    double v[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) dst.a[q][s] = src.a[q][o];
-    dst.mass[s] = src.mass[o];
+    for (int q = 0; q < 6; ++q) { v[q] = src.a[q][o]; dst.a[q][s] = v[q]; }
+    const float m = src.mass[o];
+    dst.mass[s] = m;
     dst.pid[s] = slot_key[s];
-    (void)cell_id_old;
+    flip_prec r;
+    r.x = v[0]; r.y = v[1]; r.z = v[2]; r.vx = v[3]; r.vy = v[4]; r.vz = v[5];
+    r.mass = m; r.pad0 = r.pad1 = r.pad2 = 0.f;
+    prec[s] = r;
+}
+// refresh of the packed records when the SoA arrays changed without a re-sort (velocities after G2P)
+__global__ void k_pack_records(long long n, ParticlePtrs src, flip_prec *__restrict__ prec) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    flip_prec r;
+    r.x = src.a[0][s]; r.y = src.a[1][s]; r.z = src.a[2][s]; r.vx = src.a[3][s]; r.vy = src.a[4][s]; r.vz = src.a[5][s];
+    r.mass = src.mass[s]; r.pad0 = r.pad1 = r.pad2 = 0.f;
+    prec[s] = r;
 }
 
 // Occupancy bands: bit0 = within 1 cell of a particle cell, bit1 = within 2 (Chebyshev distance).
@@ -159,9 +173,10 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
         for (int q = 0; q < 6; ++q) { ps.a[q] = ctx->p[src][q]; pd.a[q] = ctx->p[dst][q]; }
         ps.mass = ctx->mass[src]; pd.mass = ctx->mass[dst];
         ps.pid = ctx->pid[src]; pd.pid = ctx->pid[dst];
-        k_reorder<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->slot_src, ctx->slot_key, ctx->cell_id, ps, pd);
+        k_reorder<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->slot_src, ctx->slot_key, ps, pd, ctx->prec);
         FLIP_LAUNCH_CHECK();
         ctx->cur = dst;
+        ctx->prec_valid = true;
     }
     k_band_x<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, ctx->cell_start, ctx->band);
     FLIP_LAUNCH_CHECK();
@@ -219,9 +234,8 @@ extern "C" int flip_binning_download(flip_ctx *ctx, int32_t *cell_id, int32_t *c
 // ascending neighbour cell id, sorted slots within a cell.
 
 __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const uint8_t *__restrict__ band,
-                      const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
-                      const double *__restrict__ vx, const double *__restrict__ vy, const double *__restrict__ vz,
-                      double *__restrict__ u, double *__restrict__ v, double *__restrict__ w, uint8_t *__restrict__ active) {
+                      const flip_prec *__restrict__ prec, double *__restrict__ u, double *__restrict__ v,
+                      double *__restrict__ w, uint8_t *__restrict__ active) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.B) return;
     if (!(band[c] & 2)) {
@@ -242,14 +256,16 @@ __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const 
             const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
             const int32_t s0 = cell_start[row + i0], s1 = cell_start[row + i1 + 1];
             for (int32_t s = s0; s < s1; ++s) {
-                const double d0 = px[s] - cx, d1 = py[s] - cy, d2 = pz[s] - cz;
+                const double2 *rec = reinterpret_cast<const double2 *>(prec + s);
+                const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2]; // (x,y) (z,vx) (vy,vz): three 16-byte loads of one line
+                const double d0 = r0.x - cx, d1 = r0.y - cy, d2 = r1.x - cz;
                 if (d0 < -1. || d0 > 1. || d1 < -1. || d1 > 1. || d2 < -1. || d2 > 1.) continue;
                 const float x0 = (float)d_hat(d0), y0 = (float)d_hat(d1), z0 = (float)d_hat(d2);
                 const float x1 = (float)d_hat(d0 + 0.5), y1 = (float)d_hat(d1 + 0.5), z1 = (float)d_hat(d2 + 0.5);
                 const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
                 if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
                     ws0 = ws0 + w0; ws1 = ws1 + w1; ws2 = ws2 + w2;
-                    a0 = a0 + w0 * vx[s]; a1 = a1 + w1 * vy[s]; a2 = a2 + w2 * vz[s];
+                    a0 = a0 + w0 * r1.y; a1 = a1 + w1 * r2.x; a2 = a2 + w2 * r2.y;
                 }
             }
         }
@@ -260,15 +276,26 @@ __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const 
     active[c] = 1;
 }
 
+static int ensure_records(flip_ctx *ctx) {
+    if (ctx->prec_valid || ctx->n == 0) return 0;
+    ParticlePtrs ps;
+    for (int q = 0; q < 6; ++q) ps.a[q] = ctx->p[ctx->cur][q];
+    ps.mass = ctx->mass[ctx->cur];
+    ps.pid = ctx->pid[ctx->cur];
+    k_pack_records<<<flip_grid_blocks(ctx->n), FLIP_BLOCK, 0, ctx->stream>>>(ctx->n, ps, ctx->prec);
+    FLIP_LAUNCH_CHECK();
+    ctx->prec_valid = true;
+    return 0;
+}
+
 extern "C" int flip_p2g(flip_ctx *ctx) {
     FLIP_REQUIRE(ctx, "null context");
     FLIP_REQUIRE(ctx->binned, "flip_p2g: call flip_bin_particles first");
     FLIP_CHECK(hipSetDevice(ctx->device));
-    double **q = ctx->p[ctx->cur];
+    if (int rc = ensure_records(ctx)) return rc;
     // the gather writes the back buffer, then the buffers swap (src/FluidSimulator.cpp:74,117)
-    k_p2g<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->cell_start, ctx->band, q[0], q[1],
-                                                                   q[2], q[3], q[4], q[5], ctx->vel[1][0], ctx->vel[1][1],
-                                                                   ctx->vel[1][2], ctx->active);
+    k_p2g<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->cell_start, ctx->band, ctx->prec,
+                                                                   ctx->vel[1][0], ctx->vel[1][1], ctx->vel[1][2], ctx->active);
     FLIP_LAUNCH_CHECK();
     for (int a = 0; a < 3; ++a) std::swap(ctx->vel[0][a], ctx->vel[1][a]);
     return 0;
@@ -333,6 +360,7 @@ extern "C" int flip_g2p(flip_ctx *ctx, float ratio) {
                                                                    ctx->vel[0][0], ctx->vel[0][1], ctx->vel[0][2],
                                                                    ctx->vel[3][0], ctx->vel[3][1], ctx->vel[3][2], ratio);
     FLIP_LAUNCH_CHECK();
+    ctx->prec_valid = false; // velocities changed
     return 0;
 }
 
@@ -365,8 +393,7 @@ extern "C" int flip_apply_displacements(flip_ctx *ctx) {
 // Density (src/FluidSimulator.cpp:625-652, src/Functors.cpp:216-266).
 
 __global__ void k_density(GridDims g, float phi_bg, float rest, double vs3, const int32_t *__restrict__ cell_start,
-                          const uint8_t *__restrict__ band, const float *__restrict__ phi, const double *__restrict__ px,
-                          const double *__restrict__ py, const double *__restrict__ pz, const float *__restrict__ mass,
+                          const uint8_t *__restrict__ band, const float *__restrict__ phi, const flip_prec *__restrict__ prec,
                           float *__restrict__ density, int32_t *__restrict__ n_over) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.B) return;
@@ -389,11 +416,14 @@ __global__ void k_density(GridDims g, float phi_bg, float rest, double vs3, cons
                 const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
                 const int32_t s0 = cell_start[row + i0], s1 = cell_start[row + i1 + 1];
                 for (int32_t s = s0; s < s1; ++s) {
-                    const double d0 = px[s] - cx, d1 = py[s] - cy, d2 = pz[s] - cz;
+                    const double2 *rec = reinterpret_cast<const double2 *>(prec + s);
+                    const double2 r0 = rec[0];
+                    const double rz = prec[s].z;
+                    const double d0 = r0.x - cx, d1 = r0.y - cy, d2 = rz - cz;
                     if (d0 < -1. || d0 > 1. || d1 < -1. || d1 > 1. || d2 < -1. || d2 > 1.) continue;
                     const double wgt = d_hat(d0) * d_hat(d1) * d_hat(d2);
                     if (wgt > 0) {
-                        const double add = (double)0.f + wgt * (double)mass[s] / denom;
+                        const double add = (double)0.f + wgt * (double)prec[s].mass / denom;
                         dens = (float)((double)dens + add);
                     }
                 }
@@ -409,12 +439,12 @@ extern "C" int flip_density(flip_ctx *ctx, int64_t *n_overdense) {
     FLIP_REQUIRE(ctx, "null context");
     FLIP_REQUIRE(ctx->binned, "flip_density: call flip_bin_particles first");
     FLIP_CHECK(hipSetDevice(ctx->device));
-    double **q = ctx->p[ctx->cur];
+    if (int rc = ensure_records(ctx)) return rc;
     const double vs3 = pow((double)ctx->g.dx, 3);
     FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
     k_density<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->g.phi_fluid_bg, ctx->g.rest_density, vs3,
-                                                                       ctx->cell_start, ctx->band, ctx->phi_fluid, q[0], q[1],
-                                                                       q[2], ctx->mass[ctx->cur], ctx->density, ctx->d_counts + 2);
+                                                                       ctx->cell_start, ctx->band, ctx->phi_fluid, ctx->prec,
+                                                                       ctx->density, ctx->d_counts + 2);
     FLIP_LAUNCH_CHECK();
     if (n_overdense) {
         int32_t v = 0;
