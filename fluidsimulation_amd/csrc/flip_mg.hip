@@ -17,8 +17,9 @@
 #include "flip_internal.h"
 
 #define MG_OMEGA 0.8
-#define MG_COARSEST_CELLS 4096   // a level with at most this many cells is solved by one workgroup
-#define MG_COARSEST_SWEEPS 40
+#define MG_COARSEST_CELLS 4096   // one workgroup of 1024 threads, at most 4 cells per thread
+#define MG_COARSEST_LDS (60 * 1024) // its two padded vectors must fit the default dynamic LDS limit
+#define MG_COARSEST_SWEEPS 64
 
 template <class CT>
 struct MgDev {
@@ -43,14 +44,27 @@ __device__ __forceinline__ double d_mg_apply(const MgDev<CT> &L, long long c, co
     return L.diag[c] * v[c] - L.scale * acc;
 }
 
-// out = omega D^-1 b   (first sweep from a zero guess)
+// Pre-smoothing, two damped-Jacobi sweeps from a zero guess in one kernel:
+//   t = omega D^-1 b  (evaluated on the fly at the 7 stencil points),  out = t + omega D^-1 (b - A t)
 template <class CT>
-__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth_first(MgDev<CT> L, const int32_t *done, double *__restrict__ out) {
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_pre(MgDev<CT> L, const int32_t *done, double *__restrict__ out) {
     if (done && *done) return;
     const long long n = *L.n_rows;
+    const double *__restrict__ inv = L.inv, *__restrict__ b = L.b;
+#pragma unroll 2
     for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
         const long long c = L.rows[q];
-        out[c] = MG_OMEGA * L.inv[c] * L.b[c];
+        const long long sy = L.sy, sz = L.sz;
+        const double bc = b[c], ic = inv[c];
+        const double t0 = MG_OMEGA * ic * bc;
+        double acc = (double)L.cx[c] * (MG_OMEGA * inv[c - 1] * b[c - 1]);
+        acc += (double)L.cx[c + 1] * (MG_OMEGA * inv[c + 1] * b[c + 1]);
+        acc += (double)L.cy[c] * (MG_OMEGA * inv[c - sy] * b[c - sy]);
+        acc += (double)L.cy[c + sy] * (MG_OMEGA * inv[c + sy] * b[c + sy]);
+        acc += (double)L.cz[c] * (MG_OMEGA * inv[c - sz] * b[c - sz]);
+        acc += (double)L.cz[c + sz] * (MG_OMEGA * inv[c + sz] * b[c + sz]);
+        const double At = L.diag[c] * t0 - L.scale * acc;
+        out[c] = t0 + MG_OMEGA * ic * (bc - At);
     }
 }
 
@@ -86,72 +100,124 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, const int
     }
 }
 
-// coarse b = sum over the eight children of (b - A v) on the fine level; coarse x and t are not touched
+// Coarse correction + first post-smoothing sweep in one kernel: with v = in + P xc (the parent's value
+// added on the fly at the 7 stencil points), out = v + omega D^-1 (b - A v).
 template <class CT>
-__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<double> C, const int32_t *done,
-                                                           const double *__restrict__ v) {
-    if (done && *done) return;
-    const long long n = *C.n_rows;
-    for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
-        const long long cc = C.rows[q];
-        const int I = (int)(cc % C.nx);
-        const long long tq = cc / C.nx;
-        const int J = (int)(tq % C.ny), K = (int)(tq / C.ny);
-        double s = 0.0;
-#pragma unroll
-        for (int dk = 0; dk < 2; ++dk)
-#pragma unroll
-            for (int dj = 0; dj < 2; ++dj)
-#pragma unroll
-                for (int di = 0; di < 2; ++di) {
-                    const int i = 2 * I + di, j = 2 * J + dj, k = 2 * K + dk;
-                    if (i < F.nx && j < F.ny && k < F.nz) {
-                        const long long c = (long long)i + F.sy * j + F.sz * k;
-                        if (F.inv[c] != 0.0) s += F.b[c] - d_mg_apply(F, c, v);
-                    }
-                }
-        C.b[cc] = s;
-    }
-}
-
-// fine v += coarse x of the parent
-template <class CT>
-__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_prolong(MgDev<CT> F, MgDev<double> C, const int32_t *done,
-                                                          double *__restrict__ v) {
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post(MgDev<CT> F, MgDev<double> C, const int32_t *done,
+                                                       const double *__restrict__ in, double *__restrict__ out) {
     if (done && *done) return;
     const long long n = *F.n_rows;
+    const double *__restrict__ xc = C.x;
+#pragma unroll 2
     for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
         const long long c = F.rows[q];
         const int i = (int)(c % F.nx);
         const long long tq = c / F.nx;
         const int j = (int)(tq % F.ny), k = (int)(tq / F.ny);
-        const long long cc = (long long)(i >> 1) + C.sy * (j >> 1) + C.sz * (k >> 1);
-        v[c] += C.x[cc];
+        const long long pj = C.sy * (j >> 1), pk = C.sz * (k >> 1);
+        const long long pc = (i >> 1) + pj + pk;
+        // parents of the six neighbours (an arithmetic shift keeps -1 at -1: padded, and its coupling is 0)
+        const long long pxm = ((i - 1) >> 1) + pj + pk, pxp = ((i + 1) >> 1) + pj + pk;
+        const long long pym = (i >> 1) + C.sy * ((j - 1) >> 1) + pk, pyp = (i >> 1) + C.sy * ((j + 1) >> 1) + pk;
+        const long long pzm = (i >> 1) + pj + C.sz * ((k - 1) >> 1), pzp = (i >> 1) + pj + C.sz * ((k + 1) >> 1);
+        const long long sy = F.sy, sz = F.sz;
+        const double v0 = in[c] + xc[pc];
+        double acc = (double)F.cx[c] * (in[c - 1] + xc[pxm]);
+        acc += (double)F.cx[c + 1] * (in[c + 1] + xc[pxp]);
+        acc += (double)F.cy[c] * (in[c - sy] + xc[pym]);
+        acc += (double)F.cy[c + sy] * (in[c + sy] + xc[pyp]);
+        acc += (double)F.cz[c] * (in[c - sz] + xc[pzm]);
+        acc += (double)F.cz[c + sz] * (in[c + sz] + xc[pzp]);
+        const double Av = F.diag[c] * v0 - F.scale * acc;
+        out[c] = v0 + MG_OMEGA * F.inv[c] * (F.b[c] - Av);
     }
 }
 
-// Coarsest level: one workgroup, fixed even number of damped-Jacobi sweeps from zero, result in x.
-__global__ void __launch_bounds__(1024) k_mg_coarsest(MgDev<double> L, const int32_t *done) {
+// coarse b = sum over the eight children of (b - A v) on the fine level.  Eight lanes per coarse row, one per
+// child, summed by three exchange steps in a fixed order.
+template <class CT>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<double> C, const int32_t *done,
+                                                           const double *__restrict__ v) {
     if (done && *done) return;
-    const long long n = *L.n_rows;
-    for (long long q = threadIdx.x; q < n; q += blockDim.x) {
-        const long long c = L.rows[q];
-        L.x[c] = MG_OMEGA * L.inv[c] * L.b[c];
+    const long long n = *C.n_rows;
+    const int child = threadIdx.x & 7;
+    const int di = child & 1, dj = (child >> 1) & 1, dk = child >> 2;
+    for (long long q = ((long long)blockIdx.x * FLIP_BLOCK + threadIdx.x) >> 3; q < ((n + 31) & ~31LL);
+         q += ((long long)gridDim.x * FLIP_BLOCK) >> 3) {
+        double s = 0.0;
+        long long cc = 0;
+        if (q < n) {
+            cc = C.rows[q];
+            const int I = (int)(cc % C.nx);
+            const long long tq = cc / C.nx;
+            const int J = (int)(tq % C.ny), K = (int)(tq / C.ny);
+            const int i = 2 * I + di, j = 2 * J + dj, k = 2 * K + dk;
+            if (i < F.nx && j < F.ny && k < F.nz) {
+                const long long c = (long long)i + F.sy * j + F.sz * k;
+                if (F.inv[c] != 0.0) s = F.b[c] - d_mg_apply(F, c, v);
+            }
+        }
+        s += __shfl_xor(s, 1, FLIP_WAVE);
+        s += __shfl_xor(s, 2, FLIP_WAVE);
+        s += __shfl_xor(s, 4, FLIP_WAVE);
+        if (q < n && child == 0) C.b[cc] = s;
+    }
+}
+
+// Coarsest level: one workgroup, vectors in LDS (dense over the level's cells, zero-padded so that the
+// stencil needs no bounds test), a fixed number of damped-Jacobi sweeps from zero.  Each thread keeps the
+// sweep coefficients of its (at most 4) cells in registers:
+//   x' = (1 - omega) x + omega D^-1 b + sum_f (omega D^-1 c_f) x_f
+__global__ void __launch_bounds__(1024) k_mg_coarsest(MgDev<double> L, const int32_t *done, int pad) {
+    extern __shared__ double lds[];
+    if (done && *done) return;
+    const int B = (int)L.B, sy = (int)L.sy, sz = (int)L.sz;
+    double *xa = lds + pad, *xb = lds + (B + 2 * pad) + pad;
+    for (int q = threadIdx.x; q < 2 * (B + 2 * pad); q += blockDim.x) lds[q] = 0.0;
+    double k0[4], kc[4][6];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int c = threadIdx.x + m * 1024;
+        k0[m] = 0.0;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) kc[m][f] = 0.0;
+        if (c < B) {
+            const double wi = MG_OMEGA * L.inv[c];
+            k0[m] = wi * L.b[c];
+            kc[m][0] = wi * L.cx[c]; kc[m][1] = wi * L.cx[c + 1];
+            kc[m][2] = wi * L.cy[c]; kc[m][3] = wi * L.cy[c + sy];
+            kc[m][4] = wi * L.cz[c]; kc[m][5] = wi * L.cz[c + sz];
+        }
     }
     __syncthreads();
-    double *a = L.x, *b2 = L.t;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int c = threadIdx.x + m * 1024;
+        if (c < B) xa[c] = k0[m];
+    }
+    __syncthreads();
     for (int s = 1; s < MG_COARSEST_SWEEPS; ++s) {
-        for (long long q = threadIdx.x; q < n; q += blockDim.x) {
-            const long long c = L.rows[q];
-            b2[c] = a[c] + MG_OMEGA * L.inv[c] * (L.b[c] - d_mg_apply(L, c, a));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int c = threadIdx.x + m * 1024;
+            if (c < B) {
+                double v = (1.0 - MG_OMEGA) * xa[c] + k0[m];
+                v += kc[m][0] * xa[c - 1];
+                v += kc[m][1] * xa[c + 1];
+                v += kc[m][2] * xa[c - sy];
+                v += kc[m][3] * xa[c + sy];
+                v += kc[m][4] * xa[c - sz];
+                v += kc[m][5] * xa[c + sz];
+                xb[c] = v;
+            }
         }
         __syncthreads();
-        double *tmp = a; a = b2; b2 = tmp;
+        double *tmp = xa; xa = xb; xb = tmp;
     }
-    // MG_COARSEST_SWEEPS is even: sweeps 1..S-1 make an odd number of swaps, so the result sits in t
-    for (long long q = threadIdx.x; q < n; q += blockDim.x) {
-        const long long c = L.rows[q];
-        L.x[c] = a[c];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int c = threadIdx.x + m * 1024;
+        if (c < B) L.x[c] = xa[c];
     }
 }
 
@@ -231,13 +297,20 @@ void flip_mg_free(flip_ctx *ctx) {
     ctx->mg.clear();
 }
 
-// Allocates the level arrays once per context (sizes depend on the box only).
+static int mg_coarsest_pad(int nx, int ny) { return (int)(((int64_t)nx * ny + 1 + 15) / 16 * 16); }
+// can one workgroup solve a level of this size in LDS?
+static bool mg_coarsest_ok(int nx, int ny, int nz) {
+    const int64_t B = (int64_t)nx * ny * nz;
+    return B <= MG_COARSEST_CELLS && 2 * (B + 2 * mg_coarsest_pad(nx, ny)) * (int64_t)sizeof(double) <= MG_COARSEST_LDS;
+}
+
+// Allocates the level arrays once per context (sizes depend on the box only).  No level is created when the
+// box itself is small enough for the coarsest solver: multigrid has nothing to offer there.
 static int mg_ensure_levels(flip_ctx *ctx) {
     if (!ctx->mg.empty()) return 0;
     int nx = ctx->g.nx, ny = ctx->g.ny, nz = ctx->g.nz;
     for (;;) {
-        const int64_t fineB = (int64_t)nx * ny * nz;
-        if (fineB <= MG_COARSEST_CELLS || (nx <= 2 && ny <= 2 && nz <= 2)) break;
+        if (mg_coarsest_ok(nx, ny, nz) || (nx <= 2 && ny <= 2 && nz <= 2)) break;
         nx = (nx + 1) / 2; ny = (ny + 1) / 2; nz = (nz + 1) / 2;
         flip_mg_level L;
         L.nx = nx; L.ny = ny; L.nz = nz;
@@ -305,7 +378,11 @@ static int mg_coarsen_into(flip_ctx *ctx, const MgDev<CT> &F, flip_mg_level &S) 
 // Builds the coarse operators for the system currently assembled (called once per solve).
 int flip_mg_setup(flip_ctx *ctx) {
     if (int rc = mg_ensure_levels(ctx)) return rc;
-    FLIP_REQUIRE(!ctx->mg.empty(), "multigrid: the box is too small to coarsen (use the Jacobi preconditioner)");
+    if (ctx->mg.empty()) return 0; // box too small to coarsen: the caller keeps the Jacobi preconditioner
+    {
+        const flip_mg_level &S = ctx->mg.back();
+        FLIP_REQUIRE(mg_coarsest_ok(S.nx, S.ny, S.nz), "multigrid: the coarsest level does not fit one workgroup");
+    }
     if (int rc = mg_coarsen_into(ctx, mg_level0(ctx), ctx->mg[0])) return rc;
     for (size_t l = 1; l < ctx->mg.size(); ++l)
         if (int rc = mg_coarsen_into(ctx, mg_level(ctx->mg[l - 1]), ctx->mg[l])) return rc;
@@ -325,29 +402,29 @@ int flip_mg_vcycle(flip_ctx *ctx) {
     const int nblk = ctx->pcg_blocks;
     const size_t nl = ctx->mg.size();
     MgDev<float> L0 = mg_level0(ctx);
-    // ---- down ----
-    k_mg_smooth_first<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.t);
-    k_mg_smooth<float, false><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.t, L0.x, nullptr);
-    k_mg_restrict<float><<<mg_blocks(ctx, ctx->mg[0].B), FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x);
+    // ---- down: pre-smooth (result in x), restrict the residual ----
+    k_mg_pre<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.x);
+    k_mg_restrict<float><<<mg_blocks(ctx, ctx->mg[0].B * 8), FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x);
     for (size_t l = 0; l + 1 < nl; ++l) {
         MgDev<double> F = mg_level(ctx->mg[l]);
-        const int nb = mg_blocks(ctx, ctx->mg[l].B);
-        k_mg_smooth_first<double><<<nb, FLIP_BLOCK, 0, st>>>(F, done, F.t);
-        k_mg_smooth<double, false><<<nb, FLIP_BLOCK, 0, st>>>(F, done, F.t, F.x, nullptr);
-        k_mg_restrict<double><<<mg_blocks(ctx, ctx->mg[l + 1].B), FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x);
+        k_mg_pre<double><<<mg_blocks(ctx, ctx->mg[l].B), FLIP_BLOCK, 0, st>>>(F, done, F.x);
+        k_mg_restrict<double><<<mg_blocks(ctx, ctx->mg[l + 1].B * 8), FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x);
     }
     // ---- coarsest ----
-    k_mg_coarsest<<<1, 1024, 0, st>>>(mg_level(ctx->mg[nl - 1]), done);
-    // ---- up ----
+    {
+        const flip_mg_level &S = ctx->mg[nl - 1];
+        const int pad = mg_coarsest_pad(S.nx, S.ny);
+        const size_t lds = 2 * (size_t)(S.B + 2 * pad) * sizeof(double);
+        k_mg_coarsest<<<1, 1024, lds, st>>>(mg_level(S), done, pad);
+    }
+    // ---- up: correction + post-smooth 1 (x -> t), post-smooth 2 (t -> x) ----
     for (size_t l = nl - 1; l-- > 0;) {
         MgDev<double> F = mg_level(ctx->mg[l]);
         const int nb = mg_blocks(ctx, ctx->mg[l].B);
-        k_mg_prolong<double><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x);
-        k_mg_smooth<double, false><<<nb, FLIP_BLOCK, 0, st>>>(F, done, F.x, F.t, nullptr);
+        k_mg_post<double><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x, F.t);
         k_mg_smooth<double, false><<<nb, FLIP_BLOCK, 0, st>>>(F, done, F.t, F.x, nullptr);
     }
-    k_mg_prolong<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x);
-    k_mg_smooth<float, false><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.x, L0.t, nullptr);
+    k_mg_post<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x, L0.t);
     k_mg_smooth<float, true><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.t, L0.x, ctx->partial + 1 * FLIP_MAX_PCG_BLOCKS);
     FLIP_LAUNCH_CHECK();
     return 0;

@@ -576,7 +576,7 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
     FLIP_REQUIRE(ctx->sys_kind >= 0, "flip_pcg_solve: call flip_build_system first");
     FLIP_REQUIRE(precond == FLIP_PRECOND_JACOBI || precond == FLIP_PRECOND_MULTIGRID, "flip_pcg_solve: unknown preconditioner");
     // the V-cycle is a symmetric operator for the symmetric CG system; a box too small to coarsen keeps Jacobi
-    bool use_mg = precond == FLIP_PRECOND_MULTIGRID && ctx->B > 4096;
+    bool use_mg = precond == FLIP_PRECOND_MULTIGRID;
     FLIP_REQUIRE(!use_mg || ctx->sys_eliminated,
                  "flip_pcg_solve: the multigrid preconditioner needs eliminate_dependent_rows = 1 (symmetric system)");
     FLIP_REQUIRE(tol > 0.0, "flip_pcg_solve: tol must be positive");
@@ -598,6 +598,7 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
     if (use_mg) {
         FLIP_CHECK(hipMemsetAsync(ctx->ap, 0, (size_t)ctx->B * 8, st)); // V-cycle scratch on level 0
         if (int rc = flip_mg_setup(ctx)) return rc;
+        if (ctx->mg.empty()) use_mg = false;
     }
 
     PcgArgs A;
