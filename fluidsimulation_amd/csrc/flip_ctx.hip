@@ -224,6 +224,7 @@ extern "C" int flip_field_upload(flip_ctx *ctx, int field, const void *host) {
     void *p; int es;
     FLIP_REQUIRE(field_ptr(ctx, field, &p, &es) == 0, "flip_field_upload: unknown field");
     FLIP_CHECK(hipSetDevice(ctx->device));
+    if (field == FLIP_F_PHI_FLUID || field == FLIP_F_DENSITY) ctx->density_valid = false;
     FLIP_CHECK(hipMemcpyAsync(p, host, (size_t)ctx->B * es, hipMemcpyHostToDevice, ctx->stream));
     FLIP_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -288,6 +289,7 @@ extern "C" int flip_particles_upload(flip_ctx *ctx, int64_t n, const double *pos
     ctx->cur = 0;
     ctx->binned = false;
     ctx->prec_valid = false;
+    ctx->density_valid = false;
     if (n == 0) return 0;
     FLIP_CHECK(hipMemcpyAsync(ctx->stage, pos, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
     FLIP_CHECK(hipMemcpyAsync(ctx->stage + 3 * ctx->cap, vel, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));

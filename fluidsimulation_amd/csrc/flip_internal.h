@@ -76,6 +76,7 @@ struct flip_ctx {
     flip_prec *prec = nullptr;      // [cap] packed copy of the sorted particles for the gather kernels
     bool prec_valid = false;
     bool binned = false;
+    bool density_valid = false;     // ctx->density matches the current particles, sort and phi_fluid
     int64_t n_outside = 0;
 
     // ---- dense fields ----

@@ -12,14 +12,15 @@
 //                 V-cycle is a symmetric operator, as CG requires); the first sweep starts from zero.
 //   transfer    : restriction = sum of the eight child residuals (the equations are volume integrals),
 //                 prolongation = injection of the parent value.
-//   coarsest    : a fixed even number of damped-Jacobi sweeps by one workgroup.
+//   coarsest    : a fixed number of Chebyshev sweeps by one workgroup, vectors in LDS.
 // Every level keeps dense, zero-padded arrays and a compact list of its rows, like level 0.
 #include "flip_internal.h"
 
 #define MG_OMEGA 0.8
 #define MG_COARSEST_CELLS 4096   // one workgroup of 1024 threads, at most 4 cells per thread
 #define MG_COARSEST_LDS (60 * 1024) // its two padded vectors must fit the default dynamic LDS limit
-#define MG_COARSEST_SWEEPS 64
+#define MG_COARSEST_SWEEPS 24
+#define MG_COARSEST_KAPPA 100.0  // Chebyshev target interval of the coarsest solve: [2/kappa, 2]
 
 template <class CT>
 struct MgDev {
@@ -165,50 +166,62 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<d
 }
 
 // Coarsest level: one workgroup, vectors in LDS (dense over the level's cells, zero-padded so that the
-// stencil needs no bounds test), a fixed number of damped-Jacobi sweeps from zero.  Each thread keeps the
-// sweep coefficients of its (at most 4) cells in registers:
-//   x' = (1 - omega) x + omega D^-1 b + sum_f (omega D^-1 c_f) x_f
+// stencil needs no bounds test), a fixed number of Chebyshev sweeps on D^-1 A from zero.  The spectrum of
+// D^-1 A lies in (0, 2] because every level's operator is weakly diagonally dominant; the sweeps target
+// [2 / MG_COARSEST_KAPPA, 2].  A fixed polynomial in D^-1 A applied to D^-1 b is a symmetric positive
+// definite operator, as CG requires of its preconditioner.  Each thread keeps the coefficients of its
+// (at most 4) cells in registers:
+//   x_{k+1} = x_k + a_k (x_k - x_{k-1}) + c_k D^-1 (b - A x_k)
 __global__ void __launch_bounds__(1024) k_mg_coarsest(MgDev<double> L, const int32_t *done, int pad) {
     extern __shared__ double lds[];
     if (done && *done) return;
     const int B = (int)L.B, sy = (int)L.sy, sz = (int)L.sz;
     double *xa = lds + pad, *xb = lds + (B + 2 * pad) + pad;
     for (int q = threadIdx.x; q < 2 * (B + 2 * pad); q += blockDim.x) lds[q] = 0.0;
-    double k0[4], kc[4][6];
+    double k0[4], kd[4], kc[4][6];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int c = threadIdx.x + m * 1024;
-        k0[m] = 0.0;
+        k0[m] = 0.0; kd[m] = 0.0;
 #pragma unroll
         for (int f = 0; f < 6; ++f) kc[m][f] = 0.0;
         if (c < B) {
-            const double wi = MG_OMEGA * L.inv[c];
+            const double wi = L.inv[c];
             k0[m] = wi * L.b[c];
+            kd[m] = wi * L.diag[c];
             kc[m][0] = wi * L.cx[c]; kc[m][1] = wi * L.cx[c + 1];
             kc[m][2] = wi * L.cy[c]; kc[m][3] = wi * L.cy[c + sy];
             kc[m][4] = wi * L.cz[c]; kc[m][5] = wi * L.cz[c + sz];
         }
     }
+    const double lmax = 2.0, lmin = 2.0 / MG_COARSEST_KAPPA;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho = 1.0 / sigma;
     __syncthreads();
+    // x_0 = 0 (xb), x_1 = D^-1 b / theta (xa)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int c = threadIdx.x + m * 1024;
-        if (c < B) xa[c] = k0[m];
+        if (c < B) xa[c] = k0[m] / theta;
     }
     __syncthreads();
     for (int s = 1; s < MG_COARSEST_SWEEPS; ++s) {
+        const double rho_new = 1.0 / (2.0 * sigma - rho);
+        const double ak = rho_new * rho, ck = 2.0 * rho_new / delta;
+        rho = rho_new;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int c = threadIdx.x + m * 1024;
             if (c < B) {
-                double v = (1.0 - MG_OMEGA) * xa[c] + k0[m];
-                v += kc[m][0] * xa[c - 1];
-                v += kc[m][1] * xa[c + 1];
-                v += kc[m][2] * xa[c - sy];
-                v += kc[m][3] * xa[c + sy];
-                v += kc[m][4] * xa[c - sz];
-                v += kc[m][5] * xa[c + sz];
-                xb[c] = v;
+                const double xc = xa[c];
+                double res = k0[m] - kd[m] * xc;
+                res += kc[m][0] * xa[c - 1];
+                res += kc[m][1] * xa[c + 1];
+                res += kc[m][2] * xa[c - sy];
+                res += kc[m][3] * xa[c + sy];
+                res += kc[m][4] * xa[c - sz];
+                res += kc[m][5] * xa[c + sz];
+                xb[c] = xc + ak * (xc - xb[c]) + ck * res; // overwrites x_{k-1}, which only this thread reads
             }
         }
         __syncthreads();

@@ -157,6 +157,7 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
     FLIP_CHECK(hipMemsetAsync(ctx->cell_start, 0, (size_t)(B + 2) * 4, st));
     FLIP_CHECK(hipMemsetAsync(ctx->cell_fill, 0, (size_t)(B + 1) * 4, st));
     const int src = ctx->cur, dst = 1 - src;
+    ctx->density_valid = false;
     if (n > 0) {
         k_cell_ids<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(g, n, ctx->p[src][0], ctx->p[src][1], ctx->p[src][2],
                                                               ctx->cell_id, ctx->cell_start);
@@ -233,18 +234,38 @@ extern "C" int flip_binning_download(flip_ctx *ctx, int32_t *cell_id, int32_t *c
 // contiguous in the sorted arrays, so each (dy,dz) row is one slot range.  Accumulation order:
 // ascending neighbour cell id, sorted slots within a cell.
 
+// The same walk also yields the cell's density (src/FluidSimulator.cpp:625-652, src/Functors.cpp:216-266):
+// the level set does not change between the two reference calls, so the second pass over the particles is
+// saved.  flip_density() launches k_density only when the fused result is stale.
+struct DensityArgs {
+    const float *phi;
+    float *density;
+    int32_t *n_over;
+    float phi_bg, rest;
+    double vs3;
+};
+
 __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const uint8_t *__restrict__ band,
                       const flip_prec *__restrict__ prec, double *__restrict__ u, double *__restrict__ v,
-                      double *__restrict__ w, uint8_t *__restrict__ active) {
+                      double *__restrict__ w, uint8_t *__restrict__ active, DensityArgs da) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.B) return;
     if (!(band[c] & 2)) {
         u[c] = 0.0; v[c] = 0.0; w[c] = 0.0;
         active[c] = 0;
+        da.density[c] = 0.f;
         return;
     }
     int i, j, k;
     d_ijk(g, c, i, j, k);
+    const float *__restrict__ phi = da.phi;
+    const float pc = phi[c];
+    const float fw = d_frac2(d_getf(g, phi, i - 1, j, k, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i, j - 1, k, da.phi_bg), pc)
+                     + d_frac2(d_getf(g, phi, i, j, k - 1, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i + 1, j, k, da.phi_bg), pc)
+                     + d_frac2(d_getf(g, phi, i, j + 1, k, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i, j, k + 1, da.phi_bg), pc);
+    const double denom = (double)(fw / 6) * da.vs3;
+    const bool with_density = fw > 0;
+    float dens = 0.f;
     const double eps = (double)10e-37f; // background of the weight grid (src/FluidSimulator.cpp:32,77)
     double ws0 = eps, ws1 = eps, ws2 = eps, a0 = 0.0, a1 = 0.0, a2 = 0.0;
     const double cx = (double)(g.ox + i), cy = (double)(g.oy + j), cz = (double)(g.oz + k);
@@ -258,9 +279,16 @@ __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const 
             for (int32_t s = s0; s < s1; ++s) {
                 const double2 *rec = reinterpret_cast<const double2 *>(prec + s);
                 const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2]; // (x,y) (z,vx) (vy,vz): three 16-byte loads of one line
+                const float mass = prec[s].mass;
                 const double d0 = r0.x - cx, d1 = r0.y - cy, d2 = r1.x - cz;
                 if (d0 < -1. || d0 > 1. || d1 < -1. || d1 > 1. || d2 < -1. || d2 > 1.) continue;
-                const float x0 = (float)d_hat(d0), y0 = (float)d_hat(d1), z0 = (float)d_hat(d2);
+                const double hx = d_hat(d0), hy = d_hat(d1), hz = d_hat(d2);
+                const double wgt = hx * hy * hz;
+                if (with_density && wgt > 0) {
+                    const double add = (double)0.f + wgt * (double)mass / denom;
+                    dens = (float)((double)dens + add);
+                }
+                const float x0 = (float)hx, y0 = (float)hy, z0 = (float)hz;
                 const float x1 = (float)d_hat(d0 + 0.5), y1 = (float)d_hat(d1 + 0.5), z1 = (float)d_hat(d2 + 0.5);
                 const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
                 if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
@@ -274,6 +302,9 @@ __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const 
     v[c] = a1 / ws1;
     w[c] = a2 / ws2;
     active[c] = 1;
+    if (0 < fw && fw < 6) dens = dens > da.rest ? dens : da.rest;
+    da.density[c] = dens;
+    if ((double)dens > 1.5 * (double)da.rest) atomicAdd(da.n_over, 1);
 }
 
 static int ensure_records(flip_ctx *ctx) {
@@ -294,9 +325,13 @@ extern "C" int flip_p2g(flip_ctx *ctx) {
     FLIP_CHECK(hipSetDevice(ctx->device));
     if (int rc = ensure_records(ctx)) return rc;
     // the gather writes the back buffer, then the buffers swap (src/FluidSimulator.cpp:74,117)
+    DensityArgs da{ ctx->phi_fluid, ctx->density, ctx->d_counts + 2, ctx->g.phi_fluid_bg, ctx->g.rest_density,
+                    pow((double)ctx->g.dx, 3) };
+    FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
     k_p2g<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->cell_start, ctx->band, ctx->prec,
-                                                                   ctx->vel[1][0], ctx->vel[1][1], ctx->vel[1][2], ctx->active);
+                                                                   ctx->vel[1][0], ctx->vel[1][1], ctx->vel[1][2], ctx->active, da);
     FLIP_LAUNCH_CHECK();
+    ctx->density_valid = true;
     for (int a = 0; a < 3; ++a) std::swap(ctx->vel[0][a], ctx->vel[1][a]);
     return 0;
 }
@@ -386,6 +421,7 @@ extern "C" int flip_apply_displacements(flip_ctx *ctx) {
                                                                           ctx->disp[1], ctx->disp[2]);
     FLIP_LAUNCH_CHECK();
     ctx->binned = false; // positions moved: the sort is stale
+    ctx->density_valid = false;
     return 0;
 }
 
@@ -439,13 +475,16 @@ extern "C" int flip_density(flip_ctx *ctx, int64_t *n_overdense) {
     FLIP_REQUIRE(ctx, "null context");
     FLIP_REQUIRE(ctx->binned, "flip_density: call flip_bin_particles first");
     FLIP_CHECK(hipSetDevice(ctx->device));
-    if (int rc = ensure_records(ctx)) return rc;
-    const double vs3 = pow((double)ctx->g.dx, 3);
-    FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
-    k_density<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->g.phi_fluid_bg, ctx->g.rest_density, vs3,
-                                                                       ctx->cell_start, ctx->band, ctx->phi_fluid, ctx->prec,
-                                                                       ctx->density, ctx->d_counts + 2);
-    FLIP_LAUNCH_CHECK();
+    if (!ctx->density_valid) {
+        if (int rc = ensure_records(ctx)) return rc;
+        const double vs3 = pow((double)ctx->g.dx, 3);
+        FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
+        k_density<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->g.phi_fluid_bg, ctx->g.rest_density,
+                                                                           vs3, ctx->cell_start, ctx->band, ctx->phi_fluid,
+                                                                           ctx->prec, ctx->density, ctx->d_counts + 2);
+        FLIP_LAUNCH_CHECK();
+        ctx->density_valid = true;
+    }
     if (n_overdense) {
         int32_t v = 0;
         FLIP_CHECK(hipMemcpyAsync(&v, ctx->d_counts + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
