@@ -1,0 +1,52 @@
+// FluidSimulator.h -- headers/FluidSimulator.h:12-61.  Same public interface; the private step methods keep
+// the reference's names and order, and each body is one or two calls into libflip_hip.so.
+#pragma once
+
+#include "FluidDomain.h"
+#include "flipvdb.h"
+
+struct FlipSolveReport {
+    int converged = 0, iterations = 0, rows = 0;
+    double rel_residual = 0.0, seconds = 0.0;
+};
+
+class FluidSimulator {
+public:
+    FluidSimulator();
+    FluidSimulator(flipvdb::CoordBBox bbox);
+    ~FluidSimulator();
+
+    void advance_flip_pic(FluidDomain &domain, float t_frame, float flip_pic_ratio);
+    const float grav = 9.81f;
+
+    void print_velocity_field(MacGrid &grid, const char *variable_name);
+
+    static double calculate_kernel_function(flipvdb::Vec3d vec);
+    static double calculate_kernel_function(double x, double y, double z);
+    static flipvdb::Vec3d calculate_kernel_function_staggered(flipvdb::Vec3d difference);
+
+    // ---- knobs the reference hard-codes (src/FluidSimulator.cpp:31,659-660) ----
+    double solver_tolerance = 1e-15;   // Eigen CG tolerance of both solves
+    int solver_max_iterations = 0;     // <= 0: 2 * rows, the Eigen default
+    int preconditioner = FLIP_PRECOND_MULTIGRID;
+    bool density_constraint = true;    // DENSITY_CONSTRAINT_PPE
+    bool advect = true;                // FluidDomain::advectParticles inside the substep
+    bool verbose = true;               // the reference prints per-substep timings
+    int substeps_taken = 0;
+    FlipSolveReport last_divergence_solve, last_density_solve;
+
+private:
+    float compute_cfl(FluidDomain &domain);
+    void transfer_from_particles_to_grid(FluidDomain &domain);
+    void add_forces(FluidDomain &domain, float dt);
+    void extrapolate_data(FluidDomain &domain, int iterations_n);
+    void prepare_pressure_solve(FluidDomain &domain);
+    void solve_pressure_divirgence(FluidDomain &domain, float dt);
+    void solve_pressure_density(FluidDomain &domain, float dt);
+    void index_fluid_cells(FluidDomain &domain);
+    void compute_face_fractions(FluidDomain &domain);
+    void compute_density(FluidDomain &domain);
+    void transfer_from_grid_to_particles(FluidDomain &domain, float flip_pic_ratio);
+    void apply_particle_displacements(FluidDomain &domain);
+    const flipvdb::CoordBBox _bbox;
+};

@@ -145,12 +145,19 @@ int64_t flip_field_bytes(const flip_ctx *ctx, int field);
 
 /* FluidSimulator::transfer_from_particles_to_grid (src/FluidSimulator.cpp:71-118) with
  * GatherTransfer::operator() (src/Functors.cpp:10-45).  Needs flip_bin_particles first.
- * Result in velFront; FLIP_F_ACTIVE = particle cells dilated 2. */
+ * Result in velFront; FLIP_F_ACTIVE = particle cells dilated 2.  The same walk over the particles also
+ * leaves FLIP_F_DENSITY up to date for the current level set (see flip_density). */
 int flip_p2g(flip_ctx *ctx);
 /* FluidSimulator::transfer_from_grid_to_particles (src/FluidSimulator.cpp:120-135). */
 int flip_g2p(flip_ctx *ctx, float flip_pic_ratio);
 /* FluidSimulator::apply_particle_displacements (src/FluidSimulator.cpp:137-151). */
 int flip_apply_displacements(flip_ctx *ctx);
+
+/* FluidDomain::advectParticles (src/FluidDomain.cpp:63-75) with ParticleSet::advectAndEnsureOutsideObstacles
+ * (src/ParticleSet.cpp:18-45): RK3 through velFront, then particles inside the container wall or the rigid
+ * body are moved to its surface along the level-set gradient (the reference samples an OpenVDB closest-point
+ * grid; for a signed-distance level set the two agree). */
+int flip_advect_particles(flip_ctx *ctx, float dt);
 
 /* ---- grid-side glue ------------------------------------------------------------------------- */
 
@@ -177,7 +184,8 @@ int flip_index_cells(flip_ctx *ctx, int32_t *n_rows);
 int flip_face_fractions(flip_ctx *ctx);
 /* FluidSimulator::compute_density (src/FluidSimulator.cpp:625-652) + DensityCalculator
  * (src/Functors.cpp:216-266).  n_overdense (may be NULL) = cells above 1.5 rest density, the
- * cells whose particles the reference re-seeds at random (src/Functors.cpp:277-322). */
+ * cells whose particles the reference re-seeds at random (src/Functors.cpp:277-322).  flip_p2g already
+ * computes the field; this call only launches a kernel when particles, sort or level set changed since. */
 int flip_density(flip_ctx *ctx, int64_t *n_overdense);
 
 /* Attach (phi_object != NULL) or detach the rigid body that is strongly coupled in the
