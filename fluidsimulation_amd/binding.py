@@ -63,7 +63,8 @@ EXPORTS = [
     "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
     "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_project_velocity",
-    "flip_project_displacement",
+    "flip_project_displacement", "flip_set_slab", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
+    "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish",
 ]
 
 _lib = None
@@ -117,6 +118,13 @@ def load_library(path: str = LIB_PATH):
         "flip_set_profiling": (C.c_int, [vp, C.c_int]),
         "flip_project_velocity": (C.c_int, [vp, f32]),
         "flip_project_displacement": (C.c_int, [vp, f32]),
+        "flip_set_slab": (C.c_int, [vp, i32, i32]),
+        "flip_pcg_dist_buffer": (C.c_int, [vp, C.c_int, P(vp), P(i64)]),
+        "flip_pcg_dist_begin": (C.c_int, [vp, f64, i32, C.c_int]),
+        "flip_pcg_dist_direction": (C.c_int, [vp]),
+        "flip_pcg_dist_update": (C.c_int, [vp]),
+        "flip_pcg_dist_status": (C.c_int, [vp, P(i32), P(i32)]),
+        "flip_pcg_dist_finish": (C.c_int, [vp, P(PcgInfo)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -307,6 +315,35 @@ class FlipContext:
 
     def synchronize(self):
         self._check(self.lib.flip_synchronize(self.h))
+
+    # ---- z-slab decomposition of the solve ----
+    def set_slab(self, k0: int, k1: int):
+        self._check(self.lib.flip_set_slab(self.h, k0, k1))
+
+    def dist_buffer(self, which: int):
+        """(device pointer, element count) of buffer 0 (sums), 1 (z) or 2 (x); elements are doubles."""
+        ptr, n = C.c_void_p(), C.c_int64(0)
+        self._check(self.lib.flip_pcg_dist_buffer(self.h, which, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def dist_begin(self, tol: float, max_iter: int, precond: int):
+        self._check(self.lib.flip_pcg_dist_begin(self.h, tol, max_iter, precond))
+
+    def dist_direction(self):
+        self._check(self.lib.flip_pcg_dist_direction(self.h))
+
+    def dist_update(self):
+        self._check(self.lib.flip_pcg_dist_update(self.h))
+
+    def dist_status(self):
+        done, it = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.flip_pcg_dist_status(self.h, C.byref(done), C.byref(it)))
+        return done.value, it.value
+
+    def dist_finish(self) -> dict:
+        info = PcgInfo()
+        self._check(self.lib.flip_pcg_dist_finish(self.h, C.byref(info)))
+        return info.as_dict()
 
     # ---- convenience ----
     def upload_scene(self, sc):

@@ -28,6 +28,7 @@ struct flip_pcg_scalars {
     double threshold;    // tol^2 |b|^2
     double tol2;         // tol^2
     double jp[6];        // J p of the current iteration (rigid-body coupling)
+    double beta;         // beta of the last direction kernel (the slab solver's ghost planes need it)
     int32_t it_a;        // iteration the next direction kernel runs
     int32_t it_b;        // iteration the next update kernel runs
     int32_t done;        // set once converged (or |b| = 0)
@@ -127,6 +128,15 @@ struct flip_ctx {
     bool profiling = false;
     std::vector<hipEvent_t> events;
     std::vector<flip_mg_level> mg;  // coarse levels, finest first
+
+    // ---- z-slab decomposition of the solve (flip_set_slab): rows of planes [slab_k0, slab_k1) belong to this
+    // context, the other planes of the box are ghosts whose values a neighbouring rank supplies ----
+    bool slab_on = false;
+    int32_t slab_k0 = 0, slab_k1 = 0;
+    float *mg_cz = nullptr;         // z couplings without those across the slab faces: the local preconditioner's view
+    double *dist_sums = nullptr;    // [8] local sums handed to the caller's all-reduce
+    bool dist_active = false, dist_mg = false;
+    int32_t dist_max_iter = 0;
 };
 
 int flip_mg_setup(flip_ctx *ctx);   // coarse operators of the assembled system

@@ -349,7 +349,8 @@ static MgDev<float> mg_level0(flip_ctx *ctx) {
     MgDev<float> L;
     L.B = ctx->B; L.sy = ctx->g.nx; L.sz = (long long)ctx->g.nx * ctx->g.ny;
     L.nx = ctx->g.nx; L.ny = ctx->g.ny; L.nz = ctx->g.nz;
-    L.cx = ctx->cg_c[0]; L.cy = ctx->cg_c[1]; L.cz = ctx->cg_c[2];
+    // in slab mode the preconditioner is local to the rank: no coupling across the slab faces
+    L.cx = ctx->cg_c[0]; L.cy = ctx->cg_c[1]; L.cz = ctx->slab_on ? ctx->mg_cz : ctx->cg_c[2];
     L.scale = ctx->sys_s2;
     L.diag = ctx->cg_diag; L.inv = ctx->cg_inv;
     L.x = ctx->z; L.b = ctx->r; L.t = ctx->ap;   // z = M^-1 r; Ap is free between the update and direction kernels

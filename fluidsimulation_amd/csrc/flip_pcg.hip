@@ -164,16 +164,51 @@ __global__ void k_compact_chunks(int n_chunks, const int32_t *__restrict__ flag_
     if (flag_scan[q + 1] > flag_scan[q]) list[flag_scan[q]] = q;
 }
 
-__global__ void k_mark_cg_rows(long long B, const uint8_t *__restrict__ flags, int32_t *__restrict__ mark) {
+// [own_lo, own_hi): cell ids of the planes this context owns (the whole box unless flip_set_slab narrowed it)
+__global__ void k_mark_cg_rows(long long B, long long own_lo, long long own_hi, const uint8_t *__restrict__ flags,
+                               int32_t *__restrict__ mark) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c > B) return;
-    mark[c] = (c < B && (flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW) ? 1 : 0;
+    mark[c] = (c >= own_lo && c < own_hi && (flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW) ? 1 : 0;
 }
-__global__ void k_compact_cg_rows(long long B, const uint8_t *__restrict__ flags, const int32_t *__restrict__ scan,
-                                  int32_t *__restrict__ rows) {
+__global__ void k_compact_cg_rows(long long B, long long own_lo, long long own_hi, const uint8_t *__restrict__ flags,
+                                  const int32_t *__restrict__ scan, int32_t *__restrict__ rows) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= B) return;
-    if ((flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW) rows[scan[c]] = (int32_t)c;
+    if (c >= own_lo && c < own_hi && (flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW) rows[scan[c]] = (int32_t)c;
+}
+// Slab mode: ghost cells are not rows of the local CG system (diagonal and Jacobi inverse zero), and the local
+// preconditioner sees no coupling across the two slab faces (stored with the cell on the high side of a face).
+__global__ void k_slab_mask(long long B, long long sz, long long own_lo, long long own_hi, const float *__restrict__ cgz,
+                            float *__restrict__ mg_cz, double *__restrict__ cg_diag, double *__restrict__ cg_inv) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    const bool owned = c >= own_lo && c < own_hi;
+    if (!owned) { cg_diag[c] = 0.0; cg_inv[c] = 0.0; }
+    const bool on_face = (c >= own_lo && c < own_lo + sz) || (c >= own_hi && c < own_hi + sz);
+    mg_cz[c] = (owned && !on_face) ? cgz[c] : 0.f;
+}
+
+extern "C" int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(k0 >= 0 && k1 > k0 && k1 <= ctx->g.nz, "flip_set_slab: need 0 <= k0 < k1 <= nz");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    ctx->slab_on = !(k0 == 0 && k1 == ctx->g.nz);
+    ctx->slab_k0 = k0;
+    ctx->slab_k1 = k1;
+    if (ctx->slab_on && !ctx->mg_cz) {
+        // padded like the other coupling arrays: the stencil kernels read one plane beyond either end
+        float *base = nullptr;
+        FLIP_CHECK(hipMalloc((void **)&base, (size_t)(ctx->B + 2 * ctx->pad) * sizeof(float)));
+        FLIP_CHECK(hipMemset(base, 0, (size_t)(ctx->B + 2 * ctx->pad) * sizeof(float)));
+        ctx->mg_cz = base + ctx->pad;
+    }
+    if (!ctx->dist_sums) {
+        FLIP_CHECK(hipMalloc((void **)&ctx->dist_sums, 8 * sizeof(double)));
+        FLIP_CHECK(hipMemset(ctx->dist_sums, 0, 8 * sizeof(double)));
+    }
+    ctx->sys_kind = -1; // a system assembled under another ownership is stale
+    return 0;
 }
 
 extern "C" int flip_set_system_options(flip_ctx *ctx, int drop_null_rows, int eliminate_dependent_rows) {
@@ -240,10 +275,17 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     FLIP_LAUNCH_CHECK();
     FLIP_CHECK(hipMemcpyAsync(ctx->d_counts + 1, ctx->chunk_flag + ctx->n_chunks, 4, hipMemcpyDeviceToDevice, st));
     // compact list of the cells that are rows of the CG system, ascending cell id
-    k_mark_cg_rows<<<flip_grid_blocks(ctx->B + 1), FLIP_BLOCK, 0, st>>>(ctx->B, ctx->flags, ctx->cg_scan);
+    const long long plane = (long long)ctx->g.nx * ctx->g.ny;
+    const long long own_lo = ctx->slab_on ? ctx->slab_k0 * plane : 0, own_hi = ctx->slab_on ? ctx->slab_k1 * plane : ctx->B;
+    if (ctx->slab_on) {
+        k_slab_mask<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, plane, own_lo, own_hi, ctx->cg_c[2], ctx->mg_cz,
+                                                                    ctx->cg_diag, ctx->cg_inv);
+        FLIP_LAUNCH_CHECK();
+    }
+    k_mark_cg_rows<<<flip_grid_blocks(ctx->B + 1), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan);
     FLIP_LAUNCH_CHECK();
     if (int rc = flip_exclusive_scan(ctx, ctx->cg_scan, ctx->B + 1)) return rc;
-    k_compact_cg_rows<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, ctx->flags, ctx->cg_scan, ctx->cg_rows);
+    k_compact_cg_rows<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan, ctx->cg_rows);
     FLIP_LAUNCH_CHECK();
     FLIP_CHECK(hipMemcpyAsync(ctx->d_counts + 6, ctx->cg_scan + ctx->B, 4, hipMemcpyDeviceToDevice, st));
     ctx->sys_kind = kind;
@@ -421,6 +463,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_direction(PcgArgs A) {
         S->rz[it & 1] = rz;
         S->rr = rr;
         S->it_b = it;
+        S->beta = beta;
     }
     const double *__restrict__ pold = (it & 1) ? A.p0 : A.p1;
     double *__restrict__ pnew = (it & 1) ? A.p1 : A.p0;
@@ -580,6 +623,7 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
     FLIP_REQUIRE(!use_mg || ctx->sys_eliminated,
                  "flip_pcg_solve: the multigrid preconditioner needs eliminate_dependent_rows = 1 (symmetric system)");
     FLIP_REQUIRE(tol > 0.0, "flip_pcg_solve: tol must be positive");
+    FLIP_REQUIRE(!ctx->slab_on, "flip_pcg_solve: this context owns a slab of a larger system; use the flip_pcg_dist_* entry points");
     FLIP_REQUIRE(ctx->pcg_blocks % 8 == 0 && ctx->pcg_blocks <= FLIP_MAX_PCG_BLOCKS, "flip_pcg_solve: bad grid size");
     FLIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -670,6 +714,192 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
         }
         info->spmv_seconds = sp;
         info->spmv_launches = used;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-phase solver for a z-slab decomposition.  The same kernels as flip_pcg_solve; the caller (one process
+// per GPU) supplies the two things that cross ranks:
+//   - an all-reduce (sum) of the 8-double buffer flip_pcg_dist_buffer(0) after begin(), after every direction()
+//     and after every update();
+//   - an exchange of the one z plane on either side of a slab face (buffer 1: send planes slab_k0 and
+//     slab_k1-1, receive into planes slab_k0-1 and slab_k1) after begin() and after every update().
+// Every rank then sees identical scalars, takes identical branches and stops at the same iteration.  The
+// preconditioner (Jacobi, or the V-cycle over the rank's own rows) never reads across a slab face, so it is
+// block diagonal over the ranks: symmetric positive definite, no communication.  The rigid-body term is not
+// supported here.
+//
+// The global sums travel through the kernels' own reduction scheme: k_dist_gather folds this rank's
+// per-workgroup partials of the named slots into the buffer (other entries zero, so one all-reduce serves any
+// phase), k_dist_scatter writes the global value back as partial[slot][0] with zeros behind it, and the next
+// kernel's fixed-order re-reduction returns exactly that value.
+
+__global__ void __launch_bounds__(FLIP_BLOCK) k_dist_gather(const double *__restrict__ partial, int nblk, int first, int count,
+                                                           double *__restrict__ sums) {
+    __shared__ double scratch[4];
+    for (int s = 0; s < 8; ++s) {
+        double v = 0.0;
+        if (s >= first && s < first + count) v = d_reduce_partials(partial + (size_t)s * FLIP_MAX_PCG_BLOCKS, nblk, scratch);
+        if (threadIdx.x == 0) sums[s] = v;
+    }
+}
+__global__ void __launch_bounds__(FLIP_BLOCK) k_dist_scatter(double *__restrict__ partial, int nblk, int first, int count,
+                                                            const double *__restrict__ sums) {
+    for (int s = first; s < first + count; ++s)
+        for (int q = threadIdx.x; q < nblk; q += FLIP_BLOCK) partial[(size_t)s * FLIP_MAX_PCG_BLOCKS + q] = q == 0 ? sums[s] : 0.0;
+}
+// After the direction kernel: the ghost planes' search direction follows the same recurrence from the
+// neighbour's z received before it; the received z is then cleared so that the preconditioner sees zeros there.
+__global__ void k_dist_ghost_direction(flip_pcg_scalars *S, long long plane, long long lo_ghost, long long hi_ghost,
+                                       double *__restrict__ z, double *__restrict__ p0, double *__restrict__ p1) {
+    if (S->done) return;
+    const int it = S->it_b;
+    const double beta = S->beta;
+    const double *__restrict__ pold = (it & 1) ? p0 : p1;
+    double *__restrict__ pnew = (it & 1) ? p1 : p0;
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= plane) return;
+    if (lo_ghost >= 0) { const long long c = lo_ghost + q; pnew[c] = z[c] + beta * pold[c]; z[c] = 0.0; }
+    if (hi_ghost >= 0) { const long long c = hi_ghost + q; pnew[c] = z[c] + beta * pold[c]; z[c] = 0.0; }
+}
+
+extern "C" int flip_pcg_dist_buffer(flip_ctx *ctx, int which, void **ptr, int64_t *count) {
+    FLIP_REQUIRE(ctx && ptr && count, "flip_pcg_dist_buffer: null argument");
+    FLIP_REQUIRE(ctx->dist_sums, "flip_pcg_dist_buffer: call flip_set_slab first");
+    switch (which) {
+    case 0: *ptr = ctx->dist_sums; *count = 8; break;
+    case 1: *ptr = ctx->z; *count = ctx->B; break;
+    case 2: *ptr = ctx->x; *count = ctx->B; break;
+    default: FLIP_REQUIRE(false, "flip_pcg_dist_buffer: unknown buffer");
+    }
+    return 0;
+}
+
+extern "C" int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, int precond) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(ctx->sys_kind >= 0, "flip_pcg_dist_begin: call flip_build_system first");
+    FLIP_REQUIRE(ctx->dist_sums, "flip_pcg_dist_begin: call flip_set_slab first");
+    FLIP_REQUIRE(precond == FLIP_PRECOND_JACOBI || precond == FLIP_PRECOND_MULTIGRID, "flip_pcg_dist_begin: unknown preconditioner");
+    FLIP_REQUIRE(ctx->sys_eliminated, "flip_pcg_dist_begin: needs eliminate_dependent_rows = 1 (symmetric system)");
+    FLIP_REQUIRE(!ctx->sys_coupled, "flip_pcg_dist_begin: the rigid-body coupling is not supported by the slab solver");
+    FLIP_REQUIRE(tol > 0.0 && max_iter > 0, "flip_pcg_dist_begin: tol and max_iter must be positive");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    flip_pcg_scalars h;
+    memset(&h, 0, sizeof h);
+    h.tol2 = tol * tol;
+    h.max_iter = max_iter;
+    FLIP_CHECK(hipMemcpyAsync(ctx->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->x, 0, (size_t)ctx->B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->z, 0, (size_t)ctx->B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->r, 0, (size_t)ctx->B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->pv[0], 0, (size_t)ctx->B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->pv[1], 0, (size_t)ctx->B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->ap, 0, (size_t)ctx->B * 8, st));
+    bool use_mg = precond == FLIP_PRECOND_MULTIGRID;
+    if (use_mg) {
+        if (int rc = flip_mg_setup(ctx)) return rc;
+        if (ctx->mg.empty()) use_mg = false;
+    }
+    ctx->dist_mg = use_mg;
+    ctx->dist_max_iter = max_iter;
+    ctx->dist_active = true;
+    PcgArgs A;
+    fill_pcg_args(ctx, A);
+    const int nblk = ctx->pcg_blocks;
+    while (ctx->events.size() < 2 + 2 * 64) {
+        hipEvent_t e;
+        FLIP_CHECK(hipEventCreate(&e));
+        ctx->events.push_back(e);
+    }
+    FLIP_CHECK(hipEventRecord(ctx->events[0], st));
+    k_pcg_init<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+    FLIP_LAUNCH_CHECK();
+    if (use_mg)
+        if (int rc = flip_mg_vcycle(ctx)) return rc;
+    k_dist_gather<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 0, 2, ctx->dist_sums);
+    FLIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int flip_pcg_dist_direction(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx && ctx->dist_active, "flip_pcg_dist_direction: no solve in progress");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    PcgArgs A;
+    fill_pcg_args(ctx, A);
+    const int nblk = ctx->pcg_blocks;
+    k_dist_scatter<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 0, 2, ctx->dist_sums);
+    k_pcg_direction<true><<<nblk, FLIP_BLOCK, 0, st>>>(A);
+    const long long plane = (long long)ctx->g.nx * ctx->g.ny;
+    const long long lo_ghost = ctx->slab_on && ctx->slab_k0 > 0 ? (ctx->slab_k0 - 1) * plane : -1;
+    const long long hi_ghost = ctx->slab_on && ctx->slab_k1 < ctx->g.nz ? ctx->slab_k1 * plane : -1;
+    if (lo_ghost >= 0 || hi_ghost >= 0)
+        k_dist_ghost_direction<<<flip_grid_blocks(plane), FLIP_BLOCK, 0, st>>>(ctx->scal, plane, lo_ghost, hi_ghost, ctx->z,
+                                                                              ctx->pv[0], ctx->pv[1]);
+    k_dist_gather<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 2, 1, ctx->dist_sums);
+    FLIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int flip_pcg_dist_update(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx && ctx->dist_active, "flip_pcg_dist_update: no solve in progress");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    PcgArgs A;
+    fill_pcg_args(ctx, A);
+    const int nblk = ctx->pcg_blocks;
+    k_dist_scatter<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 2, 1, ctx->dist_sums);
+    k_pcg_update<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+    if (ctx->dist_mg)
+        if (int rc = flip_mg_vcycle(ctx)) return rc;
+    k_dist_gather<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 0, 2, ctx->dist_sums);
+    FLIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int flip_pcg_dist_status(flip_ctx *ctx, int32_t *done, int32_t *iterations) {
+    FLIP_REQUIRE(ctx && ctx->dist_active, "flip_pcg_dist_status: no solve in progress");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    flip_pcg_scalars h;
+    FLIP_CHECK(hipMemcpyAsync(&h, ctx->scal, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    FLIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (done) *done = h.done;
+    if (iterations) *iterations = h.it_a;
+    return 0;
+}
+
+// The caller has exchanged the ghost planes of x (buffer 2) before this call: the dependent rows next to a slab
+// face read their liquid neighbours there.
+extern "C" int flip_pcg_dist_finish(flip_ctx *ctx, flip_pcg_info *info) {
+    FLIP_REQUIRE(ctx && ctx->dist_active, "flip_pcg_dist_finish: no solve in progress");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    PcgArgs A;
+    fill_pcg_args(ctx, A);
+    k_pcg_dependent<<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(A);
+    FLIP_LAUNCH_CHECK();
+    FLIP_CHECK(hipEventRecord(ctx->events[1], st));
+    flip_pcg_scalars h;
+    FLIP_CHECK(hipMemcpyAsync(&h, ctx->scal, sizeof h, hipMemcpyDeviceToHost, st));
+    int32_t counts[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    FLIP_CHECK(hipMemcpyAsync(counts, ctx->d_counts, 32, hipMemcpyDeviceToHost, st));
+    FLIP_CHECK(hipStreamSynchronize(st));
+    ctx->dist_active = false;
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->converged = h.done == 1 ? 1 : 0;
+        info->iterations = h.it_a;
+        info->rows = counts[0];
+        info->active_chunks = counts[1];
+        info->dependent_rows = counts[4];
+        info->cg_rows = counts[6];
+        info->rhs_norm_2 = sqrt(h.rhs_norm2);
+        info->rel_residual_2 = h.rhs_norm2 > 0 ? sqrt(h.rr / h.rhs_norm2) : 0.0;
+        float ms = 0.f;
+        FLIP_CHECK(hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]));
+        info->seconds = (double)ms * 1e-3;
     }
     return 0;
 }

@@ -1,0 +1,274 @@
+"""z-slab decomposition of the FLIP substep over several GPUs: one process and one FlipContext per GPU.
+
+The reference is a single-process CPU program, so nothing here has a counterpart in it.  The dense box is cut
+into slabs along z, the slowest-varying index, so a plane of a field is one contiguous block of nx*ny elements.
+Rank r owns the cells, rows and particles of planes [start[r], start[r+1]) and additionally computes on `ghost`
+planes of its neighbours' slabs on either side:
+
+  * every stage up to the assembly of the linear system, and every stage after the solve, reaches at most a
+    few cells sideways, so with the neighbours' particles and level-set values present in the ghost planes a
+    rank computes its own slab exactly with no communication at all (redundant work in the ghost planes);
+  * the solve is global: conjugate gradients over all ranks' rows with one all-reduce of <= 8 doubles after
+    each of its two kernels and one exchange of a single plane per slab face and iteration; the
+    preconditioner (the V-cycle, or point Jacobi) acts within each slab only, which keeps it symmetric
+    positive definite without communication (block Jacobi over the ranks);
+  * after the solve the ghost planes of the pressure are filled from the neighbours, after the particle update
+    the particles near a slab face are exchanged (migration and ghost copies in one message per face).
+
+The communication layer is torch.distributed: backend "nccl" (RCCL over xGMI) on GPU tensors that alias the
+library's device buffers, or "gloo" with host staging (CPU tests, or several ranks sharing one GPU).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .binding import PRECOND_JACOBI, PRECOND_MULTIGRID, SOLVE_DENSITY, SOLVE_DIVERGENCE
+
+
+class SlabLayout:
+    """Even split of nz planes over `world` ranks with `ghost` extra planes on interior faces."""
+
+    def __init__(self, nz: int, world: int, ghost: int, starts=None):
+        if starts is None:
+            starts = [(nz * r) // world for r in range(world + 1)]
+        self.nz, self.world, self.ghost = int(nz), int(world), int(ghost)
+        self.starts = [int(s) for s in starts]
+        assert self.starts[0] == 0 and self.starts[-1] == nz and len(self.starts) == world + 1
+        for r in range(world):
+            assert self.starts[r + 1] - self.starts[r] >= max(ghost, 1) or world == 1, \
+                "a slab must be at least as thick as the ghost zone, so that ghosts reach only the next rank"
+
+    def owned(self, rank: int):
+        return self.starts[rank], self.starts[rank + 1]
+
+    def extended(self, rank: int):
+        lo, hi = self.owned(rank)
+        return max(0, lo - self.ghost), min(self.nz, hi + self.ghost)
+
+    def local_owned(self, rank: int):
+        """Owned planes in the coordinates of the rank's extended box."""
+        lo, hi = self.owned(rank)
+        e0, _ = self.extended(rank)
+        return lo - e0, hi - e0
+
+
+class _DeviceArray:
+    """Exposes raw device memory through __cuda_array_interface__ so that torch can alias it."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def device_tensor(ptr: int, n: int, device: int):
+    import torch
+    return torch.as_tensor(_DeviceArray(ptr, n), device=torch.device("cuda", device))
+
+
+class Comm:
+    """Sum all-reduce and neighbour exchange over torch.distributed; stages through the host when the backend
+    cannot take the tensors as they are (gloo with device tensors)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+
+    def _native(self, t) -> bool:
+        return self.backend == "nccl" or not t.is_cuda
+
+    def all_reduce_sum(self, t):
+        if self.world == 1:
+            return
+        if self._native(t):
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+
+    def all_reduce_max(self, t):
+        if self.world == 1:
+            return
+        if self._native(t):
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX, group=self.group)
+            t.copy_(h)
+
+    def exchange(self, send_lo, recv_lo, send_hi, recv_hi):
+        """send_lo -> rank-1 (arrives in its recv_hi), send_hi -> rank+1 (arrives in its recv_lo).  Tensors
+        toward a side without a neighbour are ignored."""
+        if self.world == 1:
+            return
+        dist = self.dist
+        ops, staged = [], []
+
+        def add(kind, t, peer):
+            if self._native(t) and t.is_contiguous():
+                wire = t
+            elif kind == "send":
+                wire = t.detach().cpu().contiguous()
+            else:
+                wire = t.new_empty(t.shape, device="cpu")
+                staged.append((t, wire))
+            ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, wire, peer, self.group))
+
+        if self.rank > 0:
+            add("send", send_lo, self.rank - 1)
+            add("recv", recv_lo, self.rank - 1)
+        if self.rank < self.world - 1:
+            add("send", send_hi, self.rank + 1)
+            add("recv", recv_hi, self.rank + 1)
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for t, wire in staged:
+            t.copy_(wire)
+
+
+class SlabExchange:
+    """Plane exchanges shared by the device solver and its numpy stand-in: `self.z` and `self.x` are tensors
+    of shape (nz_local, nx*ny) over the rank's extended box."""
+
+    def _init_slab(self, layout: SlabLayout, rank: int):
+        assert layout.world == 1 or layout.ghost >= 1
+        self.layout, self.rank = layout, rank
+        self.k0, self.k1 = layout.local_owned(rank)
+        e0, e1 = layout.extended(rank)
+        o0, o1 = layout.owned(rank)
+        # ghost thickness on either side of this rank's box, and of the neighbours' boxes toward this rank
+        self.g_lo, self.g_hi = o0 - e0, e1 - o1
+        self.g_of_lower = (layout.extended(rank - 1)[1] - layout.owned(rank - 1)[1]) if rank > 0 else 0
+        self.g_of_upper = (layout.owned(rank + 1)[0] - layout.extended(rank + 1)[0]) if rank < layout.world - 1 else 0
+
+    def exchange_z(self, comm: Comm):
+        k0, k1 = self.k0, self.k1
+        comm.exchange(self.z[k0], self.z[k0 - 1] if self.g_lo else None, self.z[k1 - 1], self.z[k1] if self.g_hi else None)
+
+    def exchange_x(self, comm: Comm):
+        """Fill every ghost plane of the solution from the neighbour that owns it."""
+        k0, k1 = self.k0, self.k1
+        comm.exchange(self.x[k0:k0 + self.g_of_lower], self.x[k0 - self.g_lo:k0] if self.g_lo else None,
+                      self.x[k1 - self.g_of_upper:k1], self.x[k1:k1 + self.g_hi] if self.g_hi else None)
+
+
+class ContextSlabSolver(SlabExchange):
+    """The split-phase solver of one FlipContext (flip_pcg_dist_*) with its buffers aliased as torch tensors."""
+
+    def __init__(self, ctx, layout: SlabLayout, rank: int, device: int):
+        self._init_slab(layout, rank)
+        self.ctx = ctx
+        ctx.set_slab(self.k0, self.k1)
+        nx, ny, nz = ctx.dims
+        p, n = ctx.dist_buffer(0)
+        self.sums = device_tensor(p, n, device)
+        p, n = ctx.dist_buffer(1)
+        self.z = device_tensor(p, n, device).view(nz, nx * ny)
+        p, n = ctx.dist_buffer(2)
+        self.x = device_tensor(p, n, device).view(nz, nx * ny)
+
+    def begin(self, tol, max_iter, precond):
+        self.ctx.dist_begin(tol, max_iter, precond)
+
+    def direction(self):
+        self.ctx.dist_direction()
+
+    def update(self):
+        self.ctx.dist_update()
+
+    def status(self):
+        return self.ctx.dist_status()
+
+    def finish(self):
+        return self.ctx.dist_finish()
+
+
+def slab_pcg_solve(solver, comm: Comm, tol: float, max_iter: int, precond: int, check_every: int = 8) -> dict:
+    """Conjugate gradients over all ranks' slabs.  `solver` is a ContextSlabSolver or anything with the same
+    methods (the CPU tests drive a numpy stand-in through this very loop).  Every rank executes the same number
+    of iterations: the stop flag is a function of all-reduced values only."""
+    solver.begin(tol, max_iter, precond)
+    comm.all_reduce_sum(solver.sums)
+    solver.exchange_z(comm)
+    done = 0
+    while not done:
+        for _ in range(check_every):
+            solver.direction()
+            comm.all_reduce_sum(solver.sums)
+            solver.update()
+            comm.all_reduce_sum(solver.sums)
+            solver.exchange_z(comm)
+        done, _ = solver.status()
+    solver.exchange_x(comm)
+    return solver.finish()
+
+
+def partition_scene(sc, layout: SlabLayout, rank: int):
+    """The part of a global scene one rank holds: level sets over its extended box and the particles whose cell
+    lies in it (ghost copies included).  Positions stay in global index space; only the box origin moves."""
+    import copy
+    e0, e1 = layout.extended(rank)
+    loc = copy.copy(sc)
+    nx, ny, _ = sc.dims
+    loc.dims = (nx, ny, e1 - e0)
+    loc.origin = (sc.origin[0], sc.origin[1], sc.origin[2] + e0)
+    loc.phi_solid = np.ascontiguousarray(sc.phi_solid[e0:e1])
+    loc.phi_fluid = np.ascontiguousarray(sc.phi_fluid[e0:e1])
+    if sc.phi_object is not None:
+        loc.phi_object = np.ascontiguousarray(sc.phi_object[e0:e1])
+    cell_k = np.floor(sc.pos[:, 2] + 0.5).astype(np.int64) - sc.origin[2]
+    keep = (cell_k >= e0) & (cell_k < e1)
+    loc.pos = np.ascontiguousarray(sc.pos[keep])
+    loc.vel = np.ascontiguousarray(sc.vel[keep])
+    loc.mass = np.ascontiguousarray(sc.mass[keep])
+    o0, o1 = layout.owned(rank)
+    loc.owned = ((cell_k[keep] >= o0) & (cell_k[keep] < o1))
+    loc.global_index = np.nonzero(keep)[0]
+    return loc
+
+
+class DistributedSubstep:
+    """FlipSubstep over a slab decomposition: the same call order (src/FluidSimulator.cpp:307-446), with the two
+    solves replaced by slab_pcg_solve and a particle exchange at the end of the substep."""
+
+    def __init__(self, ctx, layout: SlabLayout, comm: Comm, device: int = 0, flip_pic_ratio: float = 0.95,
+                 tol: float = 1e-15, max_iter: int = 20000, precond: int = PRECOND_MULTIGRID,
+                 density_projection: bool = True):
+        self.ctx, self.layout, self.comm = ctx, layout, comm
+        self.solver = ContextSlabSolver(ctx, layout, comm.rank, device)
+        self.ratio, self.tol, self.max_iter, self.precond = flip_pic_ratio, tol, max_iter, precond
+        self.density_projection = density_projection
+
+    def solve(self, kind: int, dt: float) -> dict:
+        self.ctx.build_system(kind, dt)
+        return slab_pcg_solve(self.solver, self.comm, self.tol, self.max_iter, self.precond)
+
+    def step(self, dt: float) -> dict:
+        c = self.ctx
+        c.bin_particles(want_outside=False)
+        c.p2g()
+        c.mark_valid_from_active()
+        c.extrapolate(2)
+        c.update_prev()
+        c.add_forces(dt)
+        c.index_cells()
+        c.face_fractions()
+        c.density(want_count=False)
+        out = {"divergence": self.solve(SOLVE_DIVERGENCE, dt), "density": None}
+        c.project_velocity(dt)
+        if self.density_projection:
+            out["density"] = self.solve(SOLVE_DENSITY, dt)
+            c.project_displacement(dt)
+        c.extrapolate(2)
+        c.update_diff()
+        c.g2p(self.ratio)
+        if self.density_projection:
+            c.apply_displacements()
+        return out
+
+
+__all__ = ["SlabLayout", "Comm", "SlabExchange", "ContextSlabSolver", "slab_pcg_solve", "partition_scene", "DistributedSubstep",
+           "device_tensor", "PRECOND_JACOBI", "PRECOND_MULTIGRID"]

@@ -228,6 +228,27 @@ int flip_apply_operator(flip_ctx *ctx, const double *x_host, double *y_host);
  * reports their total in flip_pcg_info::spmv_seconds. */
 int flip_set_profiling(flip_ctx *ctx, int enabled);
 
+/* ---- z-slab decomposition of the solve over several GPUs (one process and one context per GPU) ----------
+ * No counterpart in the reference, which is a single-process CPU program.  Each rank's box is its slab of
+ * the global box plus ghost planes on either side; flip_set_slab names the planes [k0, k1) of the box whose
+ * rows this context owns (the default is the whole box).  It applies to the next flip_build_system.
+ *
+ * The solve is split into phases because two things cross ranks and the library does no communication of
+ * its own: the caller all-reduces (sum) buffer 0 (8 doubles) after begin(), after every direction() and
+ * after every update(); and after begin() and every update() it sends planes k0 and k1-1 of buffer 1 (the
+ * preconditioned residual, B doubles, plane k at offset k*nx*ny) to the lower / upper neighbour and receives
+ * their planes into k0-1 and k1.  Iterate direction(), update() until flip_pcg_dist_status reports done != 0
+ * (1 converged, 2 iteration cap; identical on every rank), exchange the ghost planes of buffer 2 (the
+ * solution), and call finish(), which also fills FLIP_F_PRESSURE on the dependent rows.  The preconditioner
+ * is applied per slab (block Jacobi over ranks with a V-cycle or point Jacobi inside each block). */
+int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1);
+int flip_pcg_dist_buffer(flip_ctx *ctx, int which, void **device_ptr, int64_t *count);
+int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, int precond);
+int flip_pcg_dist_direction(flip_ctx *ctx);
+int flip_pcg_dist_update(flip_ctx *ctx);
+int flip_pcg_dist_status(flip_ctx *ctx, int32_t *done, int32_t *iterations);
+int flip_pcg_dist_finish(flip_ctx *ctx, flip_pcg_info *info);
+
 /* FluidSimulator::project_divirgence_constraint (src/FluidSimulator.cpp:1017-1102). */
 int flip_project_velocity(flip_ctx *ctx, float dt);
 /* FluidSimulator::project_density_constraint (src/FluidSimulator.cpp:1104-1178). */
