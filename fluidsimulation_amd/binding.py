@@ -64,7 +64,8 @@ EXPORTS = [
     "flip_density", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
     "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_project_velocity",
     "flip_project_displacement", "flip_set_slab", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
-    "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish",
+    "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish", "flip_particles_reserve", "flip_particles_pack",
+    "flip_particles_exchange_apply",
 ]
 
 _lib = None
@@ -125,6 +126,9 @@ def load_library(path: str = LIB_PATH):
         "flip_pcg_dist_update": (C.c_int, [vp]),
         "flip_pcg_dist_status": (C.c_int, [vp, P(i32), P(i32)]),
         "flip_pcg_dist_finish": (C.c_int, [vp, P(PcgInfo)]),
+        "flip_particles_reserve": (C.c_int, [vp, i64]),
+        "flip_particles_pack": (C.c_int, [vp, i32, i32, vp, i64, P(i64)]),
+        "flip_particles_exchange_apply": (C.c_int, [vp, vp, i64, vp, i64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -315,6 +319,23 @@ class FlipContext:
 
     def synchronize(self):
         self._check(self.lib.flip_synchronize(self.h))
+
+    # ---- particle exchange of the slab decomposition (device buffers given as integer addresses) ----
+    def reserve_particles(self, capacity: int):
+        self._check(self.lib.flip_particles_reserve(self.h, int(capacity)))
+
+    def pack_particles(self, plane_lo: int, plane_hi: int, device_ptr: int, capacity: int) -> int:
+        n = C.c_int64(0)
+        self._check(self.lib.flip_particles_pack(self.h, int(plane_lo), int(plane_hi), C.c_void_p(device_ptr), int(capacity),
+                                                 C.byref(n)))
+        return n.value
+
+    def exchange_apply(self, recv_lo_ptr: int, n_lo: int, recv_hi_ptr: int, n_hi: int):
+        self._check(self.lib.flip_particles_exchange_apply(self.h, C.c_void_p(recv_lo_ptr), int(n_lo), C.c_void_p(recv_hi_ptr),
+                                                           int(n_hi)))
+
+    def particle_count(self) -> int:
+        return int(self.lib.flip_particles_count(self.h))
 
     # ---- z-slab decomposition of the solve ----
     def set_slab(self, k0: int, k1: int):

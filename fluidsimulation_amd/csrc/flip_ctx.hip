@@ -272,13 +272,22 @@ static int ensure_particle_capacity(flip_ctx *ctx, int64_t n) {
         if (e == hipSuccess) e = dalloc(&ctx->pid[b], cap);
     }
     if (e == hipSuccess) e = dalloc(&ctx->cell_id, cap);
-    if (e == hipSuccess) e = dalloc(&ctx->slot_src, cap);
-    if (e == hipSuccess) e = dalloc(&ctx->slot_key, cap);
+    if (e == hipSuccess) e = dalloc(&ctx->slot_src, cap + 1);
+    if (e == hipSuccess) e = dalloc(&ctx->slot_key, cap + 1);
     if (e == hipSuccess) e = dalloc(&ctx->stage, cap * 6);
     if (e == hipSuccess) e = dalloc(&ctx->prec, cap);
     if (e != hipSuccess) return flip_fail_hip(ctx, e, "hipMalloc of the particle arrays", __FILE__, __LINE__);
     ctx->cap = cap;
     return 0;
+}
+
+// Room for `capacity` particles before the first upload, so that a later exchange can grow the set in place.
+extern "C" int flip_particles_reserve(flip_ctx *ctx, int64_t capacity) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(capacity >= 0 && capacity < (int64_t)2000000000, "flip_particles_reserve: capacity out of range");
+    FLIP_REQUIRE(ctx->n == 0 || capacity <= ctx->cap, "flip_particles_reserve: call it before the particles are uploaded");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    return ensure_particle_capacity(ctx, capacity);
 }
 
 extern "C" int flip_particles_upload(flip_ctx *ctx, int64_t n, const double *pos, const double *vel, const float *mass) {
@@ -290,6 +299,7 @@ extern "C" int flip_particles_upload(flip_ctx *ctx, int64_t n, const double *pos
     ctx->n = n;
     ctx->cur = 0;
     ctx->binned = false;
+    ctx->slots_valid = false;
     ctx->prec_valid = false;
     ctx->density_valid = false;
     if (n == 0) return 0;

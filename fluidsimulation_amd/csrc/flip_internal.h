@@ -77,6 +77,7 @@ struct flip_ctx {
     flip_prec *prec = nullptr;      // [cap] packed copy of the sorted particles for the gather kernels
     bool prec_valid = false;
     bool binned = false;
+    bool slots_valid = false;       // cell_start still describes the slot order (no upload / exchange since the sort)
     bool density_valid = false;     // ctx->density matches the current particles, sort and phi_fluid
     int64_t n_outside = 0;
 

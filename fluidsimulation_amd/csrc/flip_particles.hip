@@ -186,6 +186,7 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
     k_band_axis<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, 2, ctx->tmp_u8, ctx->band);
     FLIP_LAUNCH_CHECK();
     ctx->binned = true;
+    ctx->slots_valid = true;
     if (n_outside) {
         int32_t ends[2];
         FLIP_CHECK(hipMemcpyAsync(ends, ctx->cell_start + B, 8, hipMemcpyDeviceToHost, st));
@@ -421,6 +422,146 @@ extern "C" int flip_apply_displacements(flip_ctx *ctx) {
                                                                           ctx->disp[1], ctx->disp[2]);
     FLIP_LAUNCH_CHECK();
     ctx->binned = false; // positions moved: the sort is stale
+    ctx->density_valid = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Particle exchange of the z-slab decomposition (no counterpart in the reference).  A rank is authoritative
+// for the particles that the last sort placed in cells of its owned planes: one contiguous run of slots,
+// because the sort is by cell id and z is the slowest index.  After the particle update it (1) packs those of
+// them that now lie in a neighbour's extended slab into 64-byte records (migrants and the neighbour's future
+// ghost copies alike), in slot order, and (2) rebuilds its own set from the authoritative particles still inside
+// its box plus the records received.  Old ghost copies are dropped: their owners send fresh ones.
+// Particles in the outside bin (beyond the box in x or y) stay with the rank whose owned planes contain them.
+
+__device__ __forceinline__ int d_plane_of(double z, int oz) { return (int)floor(z + 0.5) - oz; }
+
+__global__ void k_flag_send(long long n, const double *__restrict__ z, const int32_t *__restrict__ cell_start, long long c_lo,
+                            long long c_hi, int oz, int plane_lo, int plane_hi, int32_t *__restrict__ flag) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n) return;
+    if (s == n) { flag[s] = 0; return; }
+    const int pl = d_plane_of(z[s], oz);
+    flag[s] = (s >= cell_start[c_lo] && s < cell_start[c_hi] && pl >= plane_lo && pl < plane_hi) ? 1 : 0;
+}
+__global__ void k_pack_send(long long n, const int32_t *__restrict__ scan, ParticlePtrs src, flip_prec *__restrict__ out,
+                            long long capacity) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int32_t o = scan[s];
+    if (scan[s + 1] == o || o >= capacity) return;
+    flip_prec r;
+    r.x = src.a[0][s]; r.y = src.a[1][s]; r.z = src.a[2][s]; r.vx = src.a[3][s]; r.vy = src.a[4][s]; r.vz = src.a[5][s];
+    r.mass = src.mass[s]; r.pad0 = r.pad1 = r.pad2 = 0.f;
+    out[o] = r;
+}
+__global__ void k_flag_keep(long long n, const double *__restrict__ z, const int32_t *__restrict__ cell_start, long long c_lo,
+                            long long c_hi, long long B, int oz, int k0, int k1, int nz, int has_lower, int has_upper,
+                            int32_t *__restrict__ flag) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n) return;
+    if (s == n) { flag[s] = 0; return; }
+    const int pl = d_plane_of(z[s], oz);
+    int keep = 0;
+    if (s >= cell_start[c_lo] && s < cell_start[c_hi]) keep = (pl >= 0 || !has_lower) && (pl < nz || !has_upper);
+    else if (s >= cell_start[B]) keep = (pl >= k0 || !has_lower) && (pl < k1 || !has_upper);
+    flag[s] = keep;
+}
+__global__ void k_compact_keep(long long n, const int32_t *__restrict__ scan, ParticlePtrs src, ParticlePtrs dst) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int32_t o = scan[s];
+    if (scan[s + 1] == o) return;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dst.a[q][o] = src.a[q][s];
+    dst.mass[o] = src.mass[s];
+    dst.pid[o] = o;
+}
+__global__ void k_unpack_recv(long long m, const flip_prec *__restrict__ in, ParticlePtrs dst, long long offset) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= m) return;
+    const flip_prec r = in[s];
+    const long long o = offset + s;
+    dst.a[0][o] = r.x; dst.a[1][o] = r.y; dst.a[2][o] = r.z; dst.a[3][o] = r.vx; dst.a[4][o] = r.vy; dst.a[5][o] = r.vz;
+    dst.mass[o] = r.mass;
+    dst.pid[o] = (int32_t)o;
+}
+
+static ParticlePtrs particle_ptrs(flip_ctx *ctx, int buffer) {
+    ParticlePtrs ps;
+    for (int q = 0; q < 6; ++q) ps.a[q] = ctx->p[buffer][q];
+    ps.mass = ctx->mass[buffer];
+    ps.pid = ctx->pid[buffer];
+    return ps;
+}
+
+extern "C" int flip_particles_pack(flip_ctx *ctx, int32_t plane_lo, int32_t plane_hi, void *device_out, int64_t capacity,
+                                   int64_t *count) {
+    FLIP_REQUIRE(ctx && count, "flip_particles_pack: null argument");
+    FLIP_REQUIRE(ctx->slots_valid, "flip_particles_pack: no valid sort (call flip_bin_particles earlier in the substep)");
+    FLIP_REQUIRE(device_out || capacity == 0, "flip_particles_pack: null buffer");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t n = ctx->n;
+    *count = 0;
+    if (n == 0) return 0;
+    const long long plane = (long long)ctx->g.nx * ctx->g.ny;
+    const int k0 = ctx->slab_on ? ctx->slab_k0 : 0, k1 = ctx->slab_on ? ctx->slab_k1 : ctx->g.nz;
+    k_flag_send<<<flip_grid_blocks(n + 1), FLIP_BLOCK, 0, st>>>(n, ctx->p[ctx->cur][2], ctx->cell_start, k0 * plane, k1 * plane,
+                                                               ctx->g.oz, plane_lo, plane_hi, ctx->slot_src);
+    FLIP_LAUNCH_CHECK();
+    if (int rc = flip_exclusive_scan(ctx, ctx->slot_src, n + 1)) return rc;
+    k_pack_send<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->slot_src, particle_ptrs(ctx, ctx->cur), (flip_prec *)device_out,
+                                                           capacity);
+    FLIP_LAUNCH_CHECK();
+    int32_t total = 0;
+    FLIP_CHECK(hipMemcpyAsync(&total, ctx->slot_src + n, 4, hipMemcpyDeviceToHost, st));
+    FLIP_CHECK(hipStreamSynchronize(st));
+    FLIP_REQUIRE(total <= capacity, "flip_particles_pack: the send buffer is too small");
+    *count = total;
+    return 0;
+}
+
+extern "C" int flip_particles_exchange_apply(flip_ctx *ctx, const void *recv_lo, int64_t n_lo, const void *recv_hi, int64_t n_hi) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(ctx->slots_valid || ctx->n == 0, "flip_particles_exchange_apply: no valid sort");
+    FLIP_REQUIRE(n_lo >= 0 && n_hi >= 0 && (recv_lo || n_lo == 0) && (recv_hi || n_hi == 0), "flip_particles_exchange_apply: bad receive buffers");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t n = ctx->n;
+    const long long plane = (long long)ctx->g.nx * ctx->g.ny;
+    const int k0 = ctx->slab_on ? ctx->slab_k0 : 0, k1 = ctx->slab_on ? ctx->slab_k1 : ctx->g.nz;
+    int32_t n_keep = 0;
+    const int src = ctx->cur, dst = 1 - src;
+    if (n > 0) {
+        k_flag_keep<<<flip_grid_blocks(n + 1), FLIP_BLOCK, 0, st>>>(n, ctx->p[src][2], ctx->cell_start, k0 * plane, k1 * plane, ctx->B,
+                                                                   ctx->g.oz, k0, k1, ctx->g.nz, k0 > 0 ? 1 : 0,
+                                                                   k1 < ctx->g.nz ? 1 : 0, ctx->slot_src);
+        FLIP_LAUNCH_CHECK();
+        if (int rc = flip_exclusive_scan(ctx, ctx->slot_src, n + 1)) return rc;
+        FLIP_CHECK(hipMemcpyAsync(&n_keep, ctx->slot_src + n, 4, hipMemcpyDeviceToHost, st));
+        FLIP_CHECK(hipStreamSynchronize(st));
+    }
+    const int64_t n_new = (int64_t)n_keep + n_lo + n_hi;
+    FLIP_REQUIRE(n_new <= ctx->cap, "flip_particles_exchange_apply: particle capacity exceeded (flip_particles_reserve more before the upload)");
+    if (n > 0) {
+        k_compact_keep<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->slot_src, particle_ptrs(ctx, src), particle_ptrs(ctx, dst));
+        FLIP_LAUNCH_CHECK();
+    }
+    if (n_lo > 0) {
+        k_unpack_recv<<<flip_grid_blocks(n_lo), FLIP_BLOCK, 0, st>>>(n_lo, (const flip_prec *)recv_lo, particle_ptrs(ctx, dst), n_keep);
+        FLIP_LAUNCH_CHECK();
+    }
+    if (n_hi > 0) {
+        k_unpack_recv<<<flip_grid_blocks(n_hi), FLIP_BLOCK, 0, st>>>(n_hi, (const flip_prec *)recv_hi, particle_ptrs(ctx, dst), n_keep + n_lo);
+        FLIP_LAUNCH_CHECK();
+    }
+    ctx->cur = dst;
+    ctx->n = n_new;
+    ctx->binned = false;
+    ctx->slots_valid = false;
+    ctx->prec_valid = false;
     ctx->density_valid = false;
     return 0;
 }

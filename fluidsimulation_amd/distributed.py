@@ -230,6 +230,40 @@ def partition_scene(sc, layout: SlabLayout, rank: int):
     return loc
 
 
+class ParticleExchange:
+    """Migration and ghost refresh after the particle update: one count message and one payload message per
+    slab face, device to device (flip_particles_pack / flip_particles_exchange_apply)."""
+
+    RECORD_DOUBLES = 8   # 64-byte records
+
+    def __init__(self, ctx, geometry: SlabExchange, comm: Comm, device: int, capacity: int):
+        import torch
+        self.ctx, self.geo, self.comm = ctx, geometry, comm
+        self.capacity = max(int(capacity), 1)
+        dev = torch.device("cuda", device)
+        mk = lambda: torch.zeros((self.capacity, self.RECORD_DOUBLES), dtype=torch.float64, device=dev)  # noqa: E731
+        self.send_lo, self.send_hi, self.recv_lo, self.recv_hi = mk(), mk(), mk(), mk()
+        self.counts = torch.zeros(4, dtype=torch.int64, device=dev)  # send_lo, send_hi, recv_lo, recv_hi
+
+    def run(self) -> dict:
+        g, c = self.geo, self.ctx
+        big = 1 << 30
+        has_lo, has_hi = self.comm.rank > 0, self.comm.rank < self.comm.world - 1
+        # everything authoritative that now lies inside the neighbour's extended slab: migrants and its ghosts
+        n_lo = c.pack_particles(-big, g.k0 + g.g_of_lower, self.send_lo.data_ptr(), self.capacity) if has_lo else 0
+        n_hi = c.pack_particles(g.k1 - g.g_of_upper, big, self.send_hi.data_ptr(), self.capacity) if has_hi else 0
+        self.counts[0], self.counts[1] = n_lo, n_hi
+        self.comm.exchange(self.counts[0:1], self.counts[2:3], self.counts[1:2], self.counts[3:4])
+        got = self.counts.tolist()
+        m_lo, m_hi = (got[2] if has_lo else 0), (got[3] if has_hi else 0)
+        assert m_lo <= self.capacity and m_hi <= self.capacity, "particle exchange buffer too small"
+        # at least one record travels either way so that no message is empty
+        self.comm.exchange(self.send_lo[:max(n_lo, 1)], self.recv_lo[:max(m_lo, 1)], self.send_hi[:max(n_hi, 1)],
+                           self.recv_hi[:max(m_hi, 1)])
+        c.exchange_apply(self.recv_lo.data_ptr(), m_lo, self.recv_hi.data_ptr(), m_hi)
+        return {"sent": (n_lo, n_hi), "received": (m_lo, m_hi)}
+
+
 class DistributedSubstep:
     """FlipSubstep over a slab decomposition: the same call order (src/FluidSimulator.cpp:307-446), with the two
     solves replaced by slab_pcg_solve and a particle exchange at the end of the substep."""
@@ -241,6 +275,9 @@ class DistributedSubstep:
         self.solver = ContextSlabSolver(ctx, layout, comm.rank, device)
         self.ratio, self.tol, self.max_iter, self.precond = flip_pic_ratio, tol, max_iter, precond
         self.density_projection = density_projection
+        # a message holds at most the sender's authoritative particles; slabs hold similar numbers of them
+        self.exchange = ParticleExchange(ctx, self.solver, comm, device, capacity=ctx.particle_count() * 5 // 4 + 4096) \
+            if comm.world > 1 else None
 
     def solve(self, kind: int, dt: float) -> dict:
         self.ctx.build_system(kind, dt)
@@ -267,8 +304,10 @@ class DistributedSubstep:
         c.g2p(self.ratio)
         if self.density_projection:
             c.apply_displacements()
+        if self.exchange is not None:
+            out["exchange"] = self.exchange.run()
         return out
 
 
-__all__ = ["SlabLayout", "Comm", "SlabExchange", "ContextSlabSolver", "slab_pcg_solve", "partition_scene", "DistributedSubstep",
+__all__ = ["SlabLayout", "Comm", "SlabExchange", "ContextSlabSolver", "slab_pcg_solve", "partition_scene", "ParticleExchange", "DistributedSubstep",
            "device_tensor", "PRECOND_JACOBI", "PRECOND_MULTIGRID"]

@@ -249,6 +249,18 @@ int flip_pcg_dist_update(flip_ctx *ctx);
 int flip_pcg_dist_status(flip_ctx *ctx, int32_t *done, int32_t *iterations);
 int flip_pcg_dist_finish(flip_ctx *ctx, flip_pcg_info *info);
 
+/* Particle exchange of the slab decomposition.  A context is authoritative for the particles its last
+ * flip_bin_particles sorted into cells of its owned planes.  flip_particles_pack copies those of them whose
+ * cell plane (in the box's own plane numbering, which may fall outside 0..nz) now lies in
+ * [plane_lo, plane_hi) into 64-byte records {x,y,z,vx,vy,vz: f64; mass: f32; 12 bytes padding} at
+ * device_out, in slot order, and returns their number.  flip_particles_exchange_apply replaces the
+ * particle set by the authoritative particles that are still inside the box followed by the records received
+ * from the lower and the upper neighbour (device buffers); the set must be sorted again afterwards.
+ * flip_particles_reserve sizes the particle arrays before the first upload so that the set can grow. */
+int flip_particles_reserve(flip_ctx *ctx, int64_t capacity);
+int flip_particles_pack(flip_ctx *ctx, int32_t plane_lo, int32_t plane_hi, void *device_out, int64_t capacity, int64_t *count);
+int flip_particles_exchange_apply(flip_ctx *ctx, const void *recv_lo, int64_t n_lo, const void *recv_hi, int64_t n_hi);
+
 /* FluidSimulator::project_divirgence_constraint (src/FluidSimulator.cpp:1017-1102). */
 int flip_project_velocity(flip_ctx *ctx, float dt);
 /* FluidSimulator::project_density_constraint (src/FluidSimulator.cpp:1104-1178). */

@@ -247,21 +247,44 @@ def _gpu_worker(rank, port, out_dir, precond):
     from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout, partition_scene
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=WORLD)
     try:
+        _gpu_rank_body(rank, out_dir, precond)
+    except BaseException:
+        import traceback
+        with open(os.path.join(out_dir, f"error_{rank}.txt"), "w") as f:
+            f.write(traceback.format_exc())
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def _gpu_rank_body(rank, out_dir, precond):
+    import torch
+    from fluidsimulation_amd import FlipContext
+    from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout, partition_scene
+    if True:
         torch.cuda.set_device(0)
         sc = _scene_gpu()
         layout = SlabLayout(sc.dims[2], WORLD, 8)
         loc = partition_scene(sc, layout, rank)
         with FlipContext(loc.desc(), device=0) as ctx:
+            ctx.reserve_particles(2 * loc.pos.shape[0])
             ctx.upload_scene(loc)
             step = DistributedSubstep(ctx, layout, Comm(), device=0, precond=precond, max_iter=20000)
             info = step.step(0.004)
-            pos, vel = ctx.download_particles()
             p = ctx.download("pressure")
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), pos=pos[loc.owned], vel=vel[loc.owned], gi=loc.global_index[loc.owned],
-                 it_div=info["divergence"]["iterations"], it_den=info["density"]["iterations"],
-                 conv=info["divergence"]["converged"] * info["density"]["converged"], p=p)
-    finally:
-        dist.destroy_process_group()
+            # after the exchange the set holds this rank's owned particles and fresh ghost copies
+            pos, vel = ctx.download_particles()
+            o0, o1 = layout.owned(rank)
+            plane = np.floor(pos[:, 2] + 0.5).astype(np.int64) - sc.origin[2]
+            owned1 = (plane >= o0) & (plane < o1)
+            info2 = step.step(0.004)
+            pos2, vel2 = ctx.download_particles()
+            plane2 = np.floor(pos2[:, 2] + 0.5).astype(np.int64) - sc.origin[2]
+            owned2 = (plane2 >= o0) & (plane2 < o1)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), pos=pos[owned1], vel=vel[owned1], pos2=pos2[owned2], vel2=vel2[owned2],
+                 n_ghost=int((~owned1).sum()), sent=np.array(info["exchange"]["sent"]),
+                 conv=info["divergence"]["converged"] * info["density"]["converged"]
+                 * info2["divergence"]["converged"] * info2["density"]["converged"], p=p)
 
 
 def _scene_gpu():
@@ -279,7 +302,14 @@ def test_two_ranks_on_one_gpu_match_the_single_context_substep(tmp_path, precond
     from fluidsimulation_amd import FlipContext, FlipSubstep
     from fluidsimulation_amd.distributed import SlabLayout
     port = _free_port()
-    mp.spawn(_gpu_worker, args=(port, str(tmp_path), precond), nprocs=WORLD, join=True)
+    try:
+        mp.spawn(_gpu_worker, args=(port, str(tmp_path), precond), nprocs=WORLD, join=True)
+    except Exception:
+        for r in range(WORLD):
+            f = os.path.join(str(tmp_path), f"error_{r}.txt")
+            if os.path.exists(f):
+                print(f"---- rank {r} ----\n" + open(f).read())
+        raise
     sc = _scene_gpu()
     with FlipContext(sc.desc()) as ctx:
         ctx.upload_scene(sc)
@@ -288,18 +318,29 @@ def test_two_ranks_on_one_gpu_match_the_single_context_substep(tmp_path, precond
         ref_p = ctx.download("pressure")
     assert ref_info["divergence"]["converged"] == 1
     lay = SlabLayout(sc.dims[2], WORLD, 8)
-    pos = np.zeros_like(ref_pos)
-    vel = np.zeros_like(ref_vel)
-    seen = np.zeros(ref_pos.shape[0], bool)
+    from scipy.spatial import cKDTree
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        stepper = FlipSubstep(ctx, precond=precond, max_iter=20000)
+        stepper.step(0.004)
+        stepper.step(0.004)
+        ref_pos2, ref_vel2 = ctx.download_particles()
+    got = {k: [] for k in ("pos", "vel", "pos2", "vel2")}
     for r in range(WORLD):
         d = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
         assert int(d["conv"]) == 1
-        pos[d["gi"]], vel[d["gi"]] = d["pos"], d["vel"]
-        seen[d["gi"]] = True
+        assert int(d["n_ghost"]) > 0 and d["sent"].sum() > 0
+        for k in got:
+            got[k].append(d[k])
         # pressure on the owned planes, and on the ghost planes after the exchange
         e0, e1 = lay.extended(r)
         scale = np.abs(ref_p).max()
         assert np.abs(d["p"] - ref_p[e0:e1])[1:-1].max() <= 1e-7 * scale
-    assert seen.all()
-    assert np.abs(pos - ref_pos).max() < 1e-5
-    assert np.abs(vel - ref_vel).max() / np.abs(ref_vel).max() < 1e-4
+    # the owned particles of the two ranks are the whole set, each exactly once; identity by position
+    for tag, rp, rv in (("", ref_pos, ref_vel), ("2", ref_pos2, ref_vel2)):
+        pos, vel = np.concatenate(got["pos" + tag]), np.concatenate(got["vel" + tag])
+        assert pos.shape == rp.shape
+        dist, idx = cKDTree(rp).query(pos, k=1)
+        assert dist.max() < 1e-5
+        assert np.array_equal(np.sort(idx), np.arange(rp.shape[0]))
+        assert np.abs(vel - rv[idx]).max() / np.abs(rv).max() < 1e-4
