@@ -2,14 +2,17 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One "step" is one pass of the hot path (fluidsimulation_amd.substep.FlipSubstep.step: binning, P2G,
-extrapolation, forces, labels, face fractions, density, divergence solve + projection, density solve +
-projection, G2P, displacements) over the synthetic side-drop dam break at 256^3 with 8 particles per cell
-(BASELINE.json configs[3]; --n/--scene select another size for quick runs).  Inputs are generated on the host
-from a fixed seed and uploaded before the timed region.  Rank 0 prints ONE JSON line.
+One "step" is one pass of the hot path (binning, P2G + density, extrapolation, forces, labels, face fractions,
+divergence solve + projection, density solve + projection, G2P, displacements; the call order of
+src/FluidSimulator.cpp:307-446) over the synthetic side-drop dam break at 256^3 with 8 particles per cell
+(--n/--ppc select another size for quick runs).  Inputs are generated on the host from a fixed seed and uploaded
+before the timed region.  Rank 0 prints ONE JSON line.
 
-For N > 1 every rank runs the whole scene on its own GPU (independent replicas, no data-path collective):
-the z-slab decomposition of the pressure solve is not built yet, so N > 1 measures replica throughput only.
+N = 1: one context, the fused solver loop.
+N > 1: z-slab decomposition, one process per GPU (fluidsimulation_amd/distributed.py): the container is N
+times as long along z and every rank owns one 256^3-sized slab of it plus ghost planes (weak scaling); the CG
+scalars are all-reduced and one plane per slab face is exchanged every iteration over RCCL, particles near a
+face are exchanged once per step.  `value` counts slab-substeps: N x (substeps of the long domain) per second.
 """
 import argparse
 import json
@@ -24,39 +27,42 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
-DIRECTION_BYTES_PER_ROW = 53   # fused direction+SpMV kernel: read z 8, p 8, diag 8, 3 float terms 12, flags 1; write p 8, Ap 8
-ITERATION_BYTES_PER_ROW = 109  # + update kernel: read p 8, Ap 8, x 8, r 8, 1/diag 8; write x 8, r 8, z 8
+# Algorithmic bytes (minimum traffic if every array were touched once per kernel):
+DIRECTION_BYTES_PER_ROW = 53   # fused direction + SpMV: the matrix-free SpMV (read p 8, diagonal 8, 3 float couplings 12,
+                               # cell type 1; write Ap 8 = 37) plus the direction update folded into it (read z 8, write p 8)
+UPDATE_BYTES_PER_ROW = 56      # read p 8, Ap 8, x 8, r 8, 1/diag 8; write x 8, r 8 (z is rewritten by the V-cycle)
+VCYCLE_BYTES_PER_ROW = 226     # level 0: pre 44 + restrict 44 + correct/post 52 + post 52 = 192; coarse levels ~ +1/7 of a
+                               # level with double couplings (240): 34
+JACOBI_ITERATION_BYTES = DIRECTION_BYTES_PER_ROW + UPDATE_BYTES_PER_ROW + 8          # + write z
+MG_ITERATION_BYTES = DIRECTION_BYTES_PER_ROW + UPDATE_BYTES_PER_ROW + VCYCLE_BYTES_PER_ROW
+P2G_BYTES_PER_PARTICLE, P2G_BYTES_PER_BAND_CELL = 48, 24   # read pos + vel; write 3 velocity components
+G2P_BYTES_PER_PARTICLE, G2P_BYTES_PER_BAND_CELL = 72, 48   # read pos + vel, write vel; read velocity + difference grids
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=int(os.environ.get("FLIP_BENCH_N", "256")))
     ap.add_argument("--ppc", type=int, default=8)
-    ap.add_argument("--scene", default="dam_break", choices=["dam_break", "cube_drop"])
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--tol", type=float, default=1e-15)
     ap.add_argument("--max-iter", type=int, default=20000)
-    ap.add_argument("--precond", default=os.environ.get("FLIP_BENCH_PRECOND", "jacobi"), choices=["jacobi", "mg"])
+    ap.add_argument("--precond", default=os.environ.get("FLIP_BENCH_PRECOND", "mg"), choices=["jacobi", "mg"])
+    ap.add_argument("--parallel", default="auto", choices=["auto", "slabs", "replicas"],
+                    help="N > 1: z-slab decomposition of one long domain (auto) or independent replicas")
+    ap.add_argument("--ghost", type=int, default=8, help="ghost planes on either side of a slab")
+    ap.add_argument("--split-phase", action="store_true", help="N = 1: drive the solver through the split-phase entry points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=40, help="CG iterations per solve timed on the CPU")
     return ap.parse_args()
 
 
-def make_scene(args):
-    from fluidsimulation_amd import scenes
-    exact = args.n <= 64
-    if args.scene == "dam_break":
-        return scenes.dam_break(args.n, ppc=args.ppc, seed=12345, exact_levelset=exact)
-    return scenes.cube_drop(args.n, ppc=args.ppc, seed=12345, exact_levelset=exact)
-
-
-def cpu_baseline(sc, args, gpu_iters):
-    """Times the CPU oracle (OpenMP port of the same stages) on this host: every non-solver stage once at
-    full size plus `cpu_iters` CG iterations per solve, extrapolated to the iteration counts the GPU run
-    needed.  Reported beside the GPU number; it is a baseline, not a target."""
+def cpu_baseline(sc, args, jacobi_iters):
+    """Times the CPU oracle (OpenMP port of the same stages, Jacobi CG as the reference runs it) on this host:
+    every non-solver stage once at full size plus `cpu_iters` CG iterations per solve, extrapolated to the
+    iteration counts Jacobi CG needs on this scene (measured on the GPU).  A baseline, not a target."""
     from oracle import Oracle
     threads = min(os.cpu_count() or 1, 16)
     o = Oracle(sc.desc(), threads=threads)
@@ -101,16 +107,29 @@ def cpu_baseline(sc, args, gpu_iters):
         t[f"project{kind}"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     diff = o.update_diff(uvw, prev)
-    new_vel = o.g2p(sc.pos, sc.vel, uvw, diff, 0.95)
+    o.g2p(sc.pos, sc.vel, uvw, diff, 0.95)
     o.apply_displacements(sc.pos, disp)
     t["g2p"] = time.perf_counter() - t0
     fixed = sum(t.values())
-    total = fixed + t_iter[0] * gpu_iters[0] + t_iter[1] * gpu_iters[1]
+    total = fixed + t_iter[0] * jacobi_iters[0] + t_iter[1] * jacobi_iters[1]
     return {"value": 1.0 / total, "unit": "substeps/s", "cores": threads, "kind": "port",
-            "sample": f"all non-solver stages once at full size ({fixed:.2f} s) + {args.cpu_iters} CG iterations per solve "
-                      f"({t_iter[0] * 1e3:.1f}/{t_iter[1] * 1e3:.1f} ms per iteration), extrapolated to the GPU run's "
-                      f"{gpu_iters[0]}+{gpu_iters[1]} iterations",
+            "sample": f"all non-solver stages once at full size ({fixed:.2f} s) + {args.cpu_iters} Jacobi-CG iterations per "
+                      f"solve ({t_iter[0] * 1e3:.1f}/{t_iter[1] * 1e3:.1f} ms per iteration), extrapolated to the "
+                      f"{jacobi_iters[0]}+{jacobi_iters[1]} iterations Jacobi CG needs on this scene (counted on the GPU)",
             "stage_seconds": {k: round(v, 4) for k, v in t.items()}}
+
+
+def time_stage(torch, fn, reps=3):
+    """Average device time of `fn` (kernels on torch's current stream, which is the context's stream)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    total = 0.0
+    for _ in range(reps):
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        total += e0.elapsed_time(e1)
+    return total / reps * 1e-3
 
 
 def main():
@@ -127,14 +146,24 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from fluidsimulation_amd import FlipContext, FlipSubstep
+    from fluidsimulation_amd import FlipContext, FlipSubstep, PRECOND_JACOBI, PRECOND_MULTIGRID, scenes
+    from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout
 
-    sc = make_scene(args)
+    precond = PRECOND_MULTIGRID if args.precond == "mg" else PRECOND_JACOBI
+    slabs = (world > 1 and args.parallel != "replicas") or (world == 1 and args.split_phase)
+    if world > 1 and slabs:
+        layout = SlabLayout(scenes.slab_box_planes(args.n, world), world, args.ghost)
+        sc = scenes.dam_break_slab(args.n, ppc=args.ppc, seed=12345, z_repeat=world, z_planes=layout.extended(rank))
+    else:
+        sc = scenes.dam_break_slab(args.n, ppc=args.ppc, seed=12345)
+        layout = SlabLayout(sc.dims[2], 1, 0)
     ctx = FlipContext(sc.desc(), device=local)
+    ctx.reserve_particles(sc.pos.shape[0] * 5 // 4 + 4096)
     ctx.upload_scene(sc)
-    from fluidsimulation_amd import PRECOND_JACOBI, PRECOND_MULTIGRID
-    step = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter,
-                       precond=PRECOND_MULTIGRID if args.precond == "mg" else PRECOND_JACOBI)
+    if slabs:
+        step = DistributedSubstep(ctx, layout, Comm(), device=local, tol=args.tol, max_iter=args.max_iter, precond=precond)
+    else:
+        step = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=precond)
 
     def barrier():
         ctx.synchronize()
@@ -152,23 +181,59 @@ def main():
         infos.append(step.step(args.dt))
     barrier()
     elapsed = time.perf_counter() - t0
+    n_local = ctx.particle_count()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        cnt = torch.tensor([float(sc.n_cells), float(n_local), float(infos[0]["divergence"]["cg_rows"])], dtype=torch.float64,
+                           device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        tot_cells, tot_particles, tot_rows = (int(v) for v in cnt.tolist())
+    else:
+        tot_cells, tot_particles, tot_rows = sc.n_cells, n_local, infos[0]["divergence"]["cg_rows"]
+
+    # ---- per-kernel measurements on this rank, outside the timed region ----
+    solves = [i[k] for i in infos for k in ("divergence", "density") if i[k] is not None]
+    rows = solves[0]["cg_rows"]
+    iters = sum(s["iterations"] for s in solves)
+    pcg_s = sum(s["seconds"] for s in solves)
+    it_bytes = MG_ITERATION_BYTES if args.precond == "mg" else JACOBI_ITERATION_BYTES
+    pcg_gbs = iters * rows * it_bytes / pcg_s / 1e9 if pcg_s > 0 else 0.0
+    spmv_s = sum(s["spmv_seconds"] for s in solves)
+    spmv_n = sum(s["spmv_launches"] for s in solves)
+    avg_launch = spmv_s / spmv_n if spmv_n else None
+    achieved = rows * DIRECTION_BYTES_PER_ROW / avg_launch / 1e9 if avg_launch else None
+    kernels = {}
+    jacobi_iters = None
+    if rank == 0:
+        ctx.bin_particles(want_outside=False)
+        t_p2g = time_stage(torch, ctx.p2g)
+        band = int(ctx.download("active").astype(np.int64).sum())
+        ctx.update_diff()
+        t_g2p = time_stage(torch, lambda: ctx.g2p(0.95))
+        p2g_bytes = P2G_BYTES_PER_PARTICLE * n_local + P2G_BYTES_PER_BAND_CELL * band
+        g2p_bytes = G2P_BYTES_PER_PARTICLE * n_local + G2P_BYTES_PER_BAND_CELL * band
+        kernels = {
+            "k_p2g": {"bound": "hbm", "achieved": p2g_bytes / t_p2g / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": p2g_bytes / t_p2g / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_p2g * 1e6,
+                      "algorithmic_bytes": p2g_bytes, "note": "the same launch also accumulates the density field"},
+            "k_g2p": {"bound": "hbm", "achieved": g2p_bytes / t_g2p / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": g2p_bytes / t_g2p / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_g2p * 1e6,
+                      "algorithmic_bytes": g2p_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline and not slabs:
+            # iteration counts of the reference's own solver (Jacobi CG) on this scene, for the CPU extrapolation
+            probe = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=PRECOND_JACOBI).step(args.dt)
+            jacobi_iters = (probe["divergence"]["iterations"], probe["density"]["iterations"])
 
     if rank == 0:
-        solves = [i[k] for i in infos for k in ("divergence", "density") if i[k] is not None]
-        rows = solves[0]["rows"]
-        spmv_s = sum(s["spmv_seconds"] for s in solves)
-        spmv_n = sum(s["spmv_launches"] for s in solves)
-        avg_launch = spmv_s / max(spmv_n, 1)
-        achieved = rows * DIRECTION_BYTES_PER_ROW / avg_launch / 1e9 if spmv_n else 0.0
-        iters = sum(s["iterations"] for s in solves)
-        pcg_s = sum(s["seconds"] for s in solves)
-        pcg_gbs = iters * rows * ITERATION_BYTES_PER_ROW / pcg_s / 1e9 if pcg_s > 0 else 0.0
+        parallelism = "single GPU"
+        if world > 1:
+            parallelism = (f"{world} z-slabs of one {world}x long domain, ghost {args.ghost}, RCCL all-reduce + plane exchange per "
+                           f"CG iteration" if slabs else f"{world} independent replicas")
         out = {
-            "metric": "FLIP substeps/s (hot path, one MI355X per replica) + PCG GB/s",
+            "metric": "FLIP substeps/s (hot path; 256^3-sized slab per MI355X) + PCG GB/s",
             "value": world * args.steps / elapsed,
             "unit": "substeps/s",
             "n_gpus": world,
@@ -180,23 +245,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.scene} {args.n}^3, {args.ppc} particles/cell, density projection on, "
-                                   f"{args.precond} PCG tol {args.tol:g}",
-                       "cells": sc.n_cells, "particles": int(sc.pos.shape[0]), "rows": rows,
-                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
+            "config": {"workload": f"dam break {args.n}^3" + (f" x{world} along z" if world > 1 and slabs else "")
+                                   + f", {args.ppc} particles/cell, density projection on, {args.precond} PCG tol {args.tol:g}",
+                       "cells": tot_cells, "particles": tot_particles, "rows": tot_rows, "parallelism": parallelism},
             "pcg": {"iterations_per_step": iters / args.steps, "seconds_per_step": pcg_s / args.steps,
                     "effective_GBps": pcg_gbs, "pct_hbm_peak": 100.0 * pcg_gbs / HBM_PEAK_GBS,
-                    "bytes_per_row_per_iteration": ITERATION_BYTES_PER_ROW,
+                    "bytes_per_row_per_iteration": it_bytes, "rows_this_rank": rows,
                     "converged": all(s["converged"] == 1 for s in solves)},
             "roofline": {"bound": "hbm", "kernel": "k_pcg_direction", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
                          "bytes_per_row": DIRECTION_BYTES_PER_ROW, "rows_per_launch": rows,
-                         "avg_launch_us": avg_launch * 1e6, "launches_timed": spmv_n},
+                         "avg_launch_us": avg_launch * 1e6 if avg_launch else None, "launches_timed": spmv_n},
+            "roofline_other_kernels": kernels,
         }
-        if not args.no_cpu_baseline:
-            first = infos[0]
-            gi = (first["divergence"]["iterations"], first["density"]["iterations"] if first["density"] else 0)
-            out["cpu_baseline"] = cpu_baseline(sc, args, gi)
+        if jacobi_iters is not None:
+            out["cpu_baseline"] = cpu_baseline(sc, args, jacobi_iters)
         print(json.dumps(out))
     ctx.close()
     if world > 1:

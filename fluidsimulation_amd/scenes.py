@@ -69,18 +69,26 @@ def _box_sdf(x, y, z, lo, hi):
     return outside + inside
 
 
-def container(n: int, full_domain: bool = False) -> Scene:
+def container(n: int, full_domain: bool = False, z_repeat: int = 1, z_planes=None) -> Scene:
     """The inverted box level set of main.cpp:122-133: walls at index (n/4,1,n/4)..(3n/4,n-2,3n/4)
     (``full_domain``: (1,1,1)..(n-2,n-2,n-2)), narrow band of 5 voxels, positive inside the open box.
-    The dense box is the band's bounding box."""
+    The dense box is the band's bounding box.  ``z_repeat`` stretches the open box to that many times its
+    length along z (the multi-GPU benchmark scene); ``z_planes = (e0, e1)`` builds only those planes of the
+    dense box (one rank's slab)."""
     dx = np.float32(1.0) / np.float32(n)   # width / max(nx,ny,nz), main.cpp:106
     if full_domain:
         lo, hi = (1.0, 1.0, 1.0), (n - 2.0, n - 2.0, n - 2.0)
     else:
         lo, hi = (n // 4 * 1.0, 1.0, n // 4 * 1.0), (3 * n // 4 * 1.0, n - 2.0, 3 * n // 4 * 1.0)
+    hi = (hi[0], hi[1], lo[2] + z_repeat * (hi[2] - lo[2]))
     hw = SOLID_HALF_WIDTH
     origin = tuple(int(l) - hw for l in lo)
     dims = tuple(int(h) + hw - o + 1 for h, o in zip(hi, origin))
+    if z_planes is not None:
+        e0, e1 = z_planes
+        assert 0 <= e0 < e1 <= dims[2]
+        origin = (origin[0], origin[1], origin[2] + e0)
+        dims = (dims[0], dims[1], e1 - e0)
     sc = Scene(n=n, dims=dims, origin=origin, dx=float(dx), phi_solid=None, phi_solid_bg=float(-hw * dx),
                phi_fluid_bg=float(FLUID_HALF_WIDTH * dx), box_lo=lo, box_hi=hi)
     x, y, z = sc.cell_coords()
@@ -108,6 +116,32 @@ def _fill_cells(sc: Scene, cell_lo, cell_hi, ppc: int, rng: np.random.Generator,
     n = pos.shape[0]
     vel = np.zeros((n, 3), dtype=np.float64)
     # mass = density * dx^3 / spawn_counter (float arithmetic of src/FluidSource.cpp:68, pow -> double)
+    mass = np.full(n, np.float32(REST_DENSITY * float(sc.dx) ** 3 / ppc), dtype=np.float32)
+    return pos, vel, mass
+
+
+def _fill_cells_by_plane(sc: Scene, cell_lo, cell_hi, ppc: int, seed: int, margin: float = 0.05):
+    """As _fill_cells, but every z plane of cells draws from its own generator seeded by (seed, plane), and only
+    the planes inside the scene's dense box are produced: two ranks that both hold a plane (one as ghosts) get
+    identical particles in it, and no rank ever builds the whole set."""
+    k_lo = max(cell_lo[2], sc.origin[2])
+    k_hi = min(cell_hi[2], sc.origin[2] + sc.dims[2])
+    ii = np.arange(cell_lo[0], cell_hi[0])
+    jj = np.arange(cell_lo[1], cell_hi[1])
+    J, I = np.meshgrid(jj, ii, indexing="ij")
+    base = np.stack([I.ravel(), J.ravel()], axis=1).astype(np.float64)
+    lo = np.asarray(sc.box_lo) + margin
+    hi = np.asarray(sc.box_hi) - margin
+    chunks = []
+    for k in range(k_lo, k_hi):
+        rng = np.random.default_rng([seed, k])
+        centres = np.concatenate([base, np.full((base.shape[0], 1), float(k))], axis=1)
+        centres = np.repeat(centres, ppc, axis=0)
+        pos = centres + rng.uniform(-0.5, 0.5, size=centres.shape)
+        chunks.append(pos[np.all((pos > lo) & (pos < hi), axis=1)])
+    pos = np.ascontiguousarray(np.concatenate(chunks)) if chunks else np.zeros((0, 3))
+    n = pos.shape[0]
+    vel = np.zeros((n, 3), dtype=np.float64)
     mass = np.full(n, np.float32(REST_DENSITY * float(sc.dx) ** 3 / ppc), dtype=np.float32)
     return pos, vel, mass
 
@@ -173,6 +207,24 @@ def dam_break(n: int, ppc: int = 8, seed: int = 12345, exact_levelset: bool = Tr
     sc.pos, sc.vel, sc.mass = _fill_cells(sc, lo, hi, ppc, rng)
     sc.phi_fluid = fluid_levelset(sc, sc.pos) if exact_levelset else fluid_levelset_box(sc, lo, hi)
     return sc
+
+
+def dam_break_slab(n: int, ppc: int = 8, seed: int = 12345, z_repeat: int = 1, z_planes=None) -> Scene:
+    """The dam-break column in a container ``z_repeat`` times as long along z, restricted to the planes
+    ``z_planes = (e0, e1)`` of its dense box (None: all of it).  Particles come plane by plane from
+    (seed, plane)-seeded generators and the level set is the analytic stand-in, so a rank can build its slab
+    alone and neighbouring ranks agree on the planes they share."""
+    sc = container(n, z_repeat=z_repeat, z_planes=z_planes)
+    lo = (n // 4, 1, n // 4)
+    hi = (n // 2, 3 * n // 4, n // 4 + z_repeat * (n // 2) + 1)
+    sc.pos, sc.vel, sc.mass = _fill_cells_by_plane(sc, lo, hi, ppc, seed)
+    sc.phi_fluid = fluid_levelset_box(sc, lo, hi)
+    return sc
+
+
+def slab_box_planes(n: int, z_repeat: int = 1) -> int:
+    """Number of z planes of the dense box of ``dam_break_slab(n, z_repeat=z_repeat)``."""
+    return z_repeat * (n // 2) + 2 * SOLID_HALF_WIDTH + 1
 
 
 def add_sphere(sc: Scene, radius_world: float = 0.1, centre_world=(0.5, 0.5, 0.5), density: float = 250.0,
