@@ -37,9 +37,12 @@ struct flip_pcg_scalars {
 
 // Packed particle record read by the gather kernels (P2G, density): one 64-byte line per particle instead of
 // one line in each of seven SoA arrays, because neighbouring lanes walk different particle ranges.
+// The first 32 bytes decide whether a particle lies within a cell's kernel support (position) and carry the
+// mass; the second 32 bytes (velocity) are only read for the particles that pass.
 struct alignas(64) flip_prec {
-    double x, y, z, vx, vy, vz;
-    float mass, pad0, pad1, pad2;
+    double x, y, z;
+    float mass, pad0;
+    double vx, vy, vz, pad1;
 };
 
 // One coarse level of the multigrid preconditioner (flip_mg.hip): dense zero-padded arrays over the

@@ -100,7 +100,7 @@ __global__ void k_reorder(long long n, const int32_t *__restrict__ slot_src, con
     dst.pid[s] = slot_key[s];
     flip_prec r;
     r.x = v[0]; r.y = v[1]; r.z = v[2]; r.vx = v[3]; r.vy = v[4]; r.vz = v[5];
-    r.mass = m; r.pad0 = r.pad1 = r.pad2 = 0.f;
+    r.mass = m; r.pad0 = 0.f; r.pad1 = 0.0;
     prec[s] = r;
 }
 // refresh of the packed records when the SoA arrays changed without a re-sort (velocities after G2P)
@@ -109,7 +109,7 @@ __global__ void k_pack_records(long long n, ParticlePtrs src, flip_prec *__restr
     if (s >= n) return;
     flip_prec r;
     r.x = src.a[0][s]; r.y = src.a[1][s]; r.z = src.a[2][s]; r.vx = src.a[3][s]; r.vy = src.a[4][s]; r.vz = src.a[5][s];
-    r.mass = src.mass[s]; r.pad0 = r.pad1 = r.pad2 = 0.f;
+    r.mass = src.mass[s]; r.pad0 = 0.f; r.pad1 = 0.0;
     prec[s] = r;
 }
 
@@ -277,12 +277,22 @@ __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const 
             if (jj < 0 || jj >= g.ny) continue;
             const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
             const int32_t s0 = cell_start[row + i0], s1 = cell_start[row + i1 + 1];
+            if (s0 == s1) continue;
+            // Every lane reads its own record, so each 16-byte load of the wave asks the L1 for up to 64 different
+            // lines and the loop is bound by that request rate: position and mass sit in the first 32 bytes of a
+            // record (two requests per visit), the velocity half is fetched only by the lanes whose particle lies
+            // within the kernel's support (about 30 %), and the next record is requested before the current one
+            // is consumed.
+            const double2 *first = reinterpret_cast<const double2 *>(prec + s0);
+            double2 n0 = first[0], n1 = first[1]; // (x,y) (z, mass)
             for (int32_t s = s0; s < s1; ++s) {
                 const double2 *rec = reinterpret_cast<const double2 *>(prec + s);
-                const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2]; // (x,y) (z,vx) (vy,vz): three 16-byte loads of one line
-                const float mass = prec[s].mass;
+                const double2 r0 = n0, r1 = n1;
+                if (s + 1 < s1) { n0 = rec[4]; n1 = rec[5]; }
                 const double d0 = r0.x - cx, d1 = r0.y - cy, d2 = r1.x - cz;
                 if (d0 < -1. || d0 > 1. || d1 < -1. || d1 > 1. || d2 < -1. || d2 > 1.) continue;
+                const double2 r2 = rec[2], r3 = rec[3]; // (vx,vy) (vz, -)
+                const float mass = __int_as_float((int)(__double_as_longlong(r1.y) & 0xffffffffLL));
                 const double hx = d_hat(d0), hy = d_hat(d1), hz = d_hat(d2);
                 const double wgt = hx * hy * hz;
                 if (with_density && wgt > 0) {
@@ -294,7 +304,7 @@ __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const 
                 const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
                 if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
                     ws0 = ws0 + w0; ws1 = ws1 + w1; ws2 = ws2 + w2;
-                    a0 = a0 + w0 * r1.y; a1 = a1 + w1 * r2.x; a2 = a2 + w2 * r2.y;
+                    a0 = a0 + w0 * r2.x; a1 = a1 + w1 * r2.y; a2 = a2 + w2 * r3.x;
                 }
             }
         }
@@ -453,7 +463,7 @@ __global__ void k_pack_send(long long n, const int32_t *__restrict__ scan, Parti
     if (scan[s + 1] == o || o >= capacity) return;
     flip_prec r;
     r.x = src.a[0][s]; r.y = src.a[1][s]; r.z = src.a[2][s]; r.vx = src.a[3][s]; r.vy = src.a[4][s]; r.vz = src.a[5][s];
-    r.mass = src.mass[s]; r.pad0 = r.pad1 = r.pad2 = 0.f;
+    r.mass = src.mass[s]; r.pad0 = 0.f; r.pad1 = 0.0;
     out[o] = r;
 }
 __global__ void k_flag_keep(long long n, const double *__restrict__ z, const int32_t *__restrict__ cell_start, long long c_lo,

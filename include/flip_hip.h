@@ -252,7 +252,7 @@ int flip_pcg_dist_finish(flip_ctx *ctx, flip_pcg_info *info);
 /* Particle exchange of the slab decomposition.  A context is authoritative for the particles its last
  * flip_bin_particles sorted into cells of its owned planes.  flip_particles_pack copies those of them whose
  * cell plane (in the box's own plane numbering, which may fall outside 0..nz) now lies in
- * [plane_lo, plane_hi) into 64-byte records {x,y,z,vx,vy,vz: f64; mass: f32; 12 bytes padding} at
+ * [plane_lo, plane_hi) into 64-byte records {x,y,z: f64; mass: f32; 4 bytes padding; vx,vy,vz: f64; 8 bytes padding} at
  * device_out, in slot order, and returns their number.  flip_particles_exchange_apply replaces the
  * particle set by the authoritative particles that are still inside the box followed by the records received
  * from the lower and the upper neighbour (device buffers); the set must be sorted again afterwards.
