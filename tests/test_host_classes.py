@@ -132,5 +132,7 @@ def test_filled_scene_stays_inside_the_container(tmp_path):
     lo = np.array([n // 4, 1, n // 4]) - 0.5
     hi = np.array([3 * n // 4, n - 2, 3 * n // 4]) + 0.5
     assert ((data["pos1"] >= lo) & (data["pos1"] <= hi)).all()
-    assert data["pos1"][:, 1].mean() < data["pos0"][:, 1].mean()
-    assert np.abs(data["vel1"]).max() > 0.1
+    # the block rests on the floor: it moves (gravity, the density projection spreads it) but stays bounded
+    assert 0.01 < np.abs(data["vel1"]).max() < 10.0
+    summary = [l for l in r.stdout.splitlines() if l.startswith("summary")][0].split()
+    assert int(summary[summary.index("div_converged") + 1]) == 1
