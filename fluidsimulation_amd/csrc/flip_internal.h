@@ -37,11 +37,21 @@ struct flip_pcg_scalars {
 
 // Packed particle record read by the gather kernels (P2G, density): one 64-byte line per particle instead of
 // one line in each of seven SoA arrays, because neighbouring lanes walk different particle ranges.
-// The first 32 bytes decide whether a particle lies within a cell's kernel support (position) and carry the
-// mass; the second 32 bytes (velocity) are only read for the particles that pass.
+// 64-byte particle record: the wire format of the particle exchange (flip_particles_pack).
 struct alignas(64) flip_prec {
     double x, y, z;
     float mass, pad0;
+    double vx, vy, vz, pad1;
+};
+// The gather kernels read the sorted particles from two packed arrays of 32-byte halves instead: the position half
+// decides whether a particle lies within a cell's kernel support and carries the mass; the velocity half is read
+// only for the particles that pass.  Two consecutive slots share a 64-byte line in either array, so a lane that
+// walks a slot range pulls each line into L1 once for two particles.
+struct alignas(32) flip_ppos {
+    double x, y, z;
+    float mass, pad0;
+};
+struct alignas(32) flip_pvel {
     double vx, vy, vz, pad1;
 };
 
@@ -77,7 +87,7 @@ struct flip_ctx {
     int32_t *scan_tmp = nullptr;    // block sums of the scan
     int64_t scan_tmp_len = 0;
     double *stage = nullptr;        // [cap*3] upload/download staging (AoS)
-    flip_prec *prec = nullptr;      // [cap] packed copy of the sorted particles for the gather kernels
+    flip_prec *prec = nullptr;      // [cap] x 64 bytes: flip_ppos[cap] followed by flip_pvel[cap], the gather kernels' copy
     bool prec_valid = false;
     bool binned = false;
     bool slots_valid = false;       // cell_start still describes the slot order (no upload / exchange since the sort)
@@ -203,6 +213,10 @@ __device__ __forceinline__ double d_hat(double x) {
     else if (0. <= x && x <= 1.) return 1 - x;
     else return 0;
 }
+// The same function for an argument known to lie in [-1, 1], and for one known to be >= -1: fewer instructions,
+// identical bits (1 + x with x < 0 is the IEEE operation 1 - |x|).
+__device__ __forceinline__ double d_hat_in(double x) { return 1 - fabs(x); }
+__device__ __forceinline__ double d_hat_up(double x) { return x > 1. ? 0. : 1 - fabs(x); }
 // headers/util.h:200-208
 __device__ __forceinline__ float d_clampf(float a, float lo, float hi) { return a < lo ? lo : (a > hi ? hi : a); }
 // headers/util.h:493-501 (T = float)

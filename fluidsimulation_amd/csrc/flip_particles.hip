@@ -88,7 +88,7 @@ struct ParticlePtrs {
     int32_t *pid;
 };
 __global__ void k_reorder(long long n, const int32_t *__restrict__ slot_src, const int32_t *__restrict__ slot_key,
-                          ParticlePtrs src, ParticlePtrs dst, flip_prec *__restrict__ prec) {
+                          ParticlePtrs src, ParticlePtrs dst, flip_ppos *__restrict__ pm, flip_pvel *__restrict__ pv) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const int32_t o = slot_src[s];
@@ -98,20 +98,26 @@ __global__ void k_reorder(long long n, const int32_t *__restrict__ slot_src, con
     const float m = src.mass[o];
     dst.mass[s] = m;
     dst.pid[s] = slot_key[s];
-    flip_prec r;
-    r.x = v[0]; r.y = v[1]; r.z = v[2]; r.vx = v[3]; r.vy = v[4]; r.vz = v[5];
-    r.mass = m; r.pad0 = 0.f; r.pad1 = 0.0;
-    prec[s] = r;
+    flip_ppos a;
+    a.x = v[0]; a.y = v[1]; a.z = v[2]; a.mass = m; a.pad0 = 0.f;
+    flip_pvel b;
+    b.vx = v[3]; b.vy = v[4]; b.vz = v[5]; b.pad1 = 0.0;
+    pm[s] = a;
+    pv[s] = b;
 }
 // refresh of the packed records when the SoA arrays changed without a re-sort (velocities after G2P)
-__global__ void k_pack_records(long long n, ParticlePtrs src, flip_prec *__restrict__ prec) {
+__global__ void k_pack_records(long long n, ParticlePtrs src, flip_ppos *__restrict__ pm, flip_pvel *__restrict__ pv) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
-    flip_prec r;
-    r.x = src.a[0][s]; r.y = src.a[1][s]; r.z = src.a[2][s]; r.vx = src.a[3][s]; r.vy = src.a[4][s]; r.vz = src.a[5][s];
-    r.mass = src.mass[s]; r.pad0 = 0.f; r.pad1 = 0.0;
-    prec[s] = r;
+    flip_ppos a;
+    a.x = src.a[0][s]; a.y = src.a[1][s]; a.z = src.a[2][s]; a.mass = src.mass[s]; a.pad0 = 0.f;
+    flip_pvel b;
+    b.vx = src.a[3][s]; b.vy = src.a[4][s]; b.vz = src.a[5][s]; b.pad1 = 0.0;
+    pm[s] = a;
+    pv[s] = b;
 }
+static inline flip_ppos *packed_pos(flip_ctx *ctx) { return reinterpret_cast<flip_ppos *>(ctx->prec); }
+static inline flip_pvel *packed_vel(flip_ctx *ctx) { return reinterpret_cast<flip_pvel *>(reinterpret_cast<flip_ppos *>(ctx->prec) + ctx->cap); }
 
 // Occupancy bands: bit0 = within 1 cell of a particle cell, bit1 = within 2 (Chebyshev distance).
 // Box dilation is separable: one pass per axis.
@@ -174,7 +180,7 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
         for (int q = 0; q < 6; ++q) { ps.a[q] = ctx->p[src][q]; pd.a[q] = ctx->p[dst][q]; }
         ps.mass = ctx->mass[src]; pd.mass = ctx->mass[dst];
         ps.pid = ctx->pid[src]; pd.pid = ctx->pid[dst];
-        k_reorder<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->slot_src, ctx->slot_key, ps, pd, ctx->prec);
+        k_reorder<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->slot_src, ctx->slot_key, ps, pd, packed_pos(ctx), packed_vel(ctx));
         FLIP_LAUNCH_CHECK();
         ctx->cur = dst;
         ctx->prec_valid = true;
@@ -247,8 +253,8 @@ struct DensityArgs {
 };
 
 __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const uint8_t *__restrict__ band,
-                      const flip_prec *__restrict__ prec, double *__restrict__ u, double *__restrict__ v,
-                      double *__restrict__ w, uint8_t *__restrict__ active, DensityArgs da) {
+                      const flip_ppos *__restrict__ pm, const flip_pvel *__restrict__ pv, double *__restrict__ u,
+                      double *__restrict__ v, double *__restrict__ w, uint8_t *__restrict__ active, DensityArgs da) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.B) return;
     if (!(band[c] & 2)) {
@@ -278,29 +284,35 @@ __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const 
             const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
             const int32_t s0 = cell_start[row + i0], s1 = cell_start[row + i1 + 1];
             if (s0 == s1) continue;
-            // Every lane reads its own record, so each 16-byte load of the wave asks the L1 for up to 64 different
-            // lines and the loop is bound by that request rate: position and mass sit in the first 32 bytes of a
-            // record (two requests per visit), the velocity half is fetched only by the lanes whose particle lies
-            // within the kernel's support (about 30 %), and the next record is requested before the current one
-            // is consumed.
-            const double2 *first = reinterpret_cast<const double2 *>(prec + s0);
+            // Every lane walks its own slot range, so each 16-byte load of the wave asks for up to 64 different
+            // lines and the loop is bound by that line traffic: position and mass come from the 32-byte position
+            // half (two consecutive slots share a line), the velocity half is fetched only by the lanes whose particle
+            // lies within the kernel's support (about 30 %), and the next position is requested before the current
+            // one is consumed.
+            const double2 *first = reinterpret_cast<const double2 *>(pm + s0);
             double2 n0 = first[0], n1 = first[1]; // (x,y) (z, mass)
             for (int32_t s = s0; s < s1; ++s) {
-                const double2 *rec = reinterpret_cast<const double2 *>(prec + s);
                 const double2 r0 = n0, r1 = n1;
-                if (s + 1 < s1) { n0 = rec[4]; n1 = rec[5]; }
+                if (s + 1 < s1) {
+                    const double2 *nxt = reinterpret_cast<const double2 *>(pm + s + 1);
+                    n0 = nxt[0]; n1 = nxt[1];
+                }
                 const double d0 = r0.x - cx, d1 = r0.y - cy, d2 = r1.x - cz;
-                if (d0 < -1. || d0 > 1. || d1 < -1. || d1 > 1. || d2 < -1. || d2 > 1.) continue;
-                const double2 r2 = rec[2], r3 = rec[3]; // (vx,vy) (vz, -)
+                if (fabs(d0) > 1. || fabs(d1) > 1. || fabs(d2) > 1.) continue;
+                const double2 *vel = reinterpret_cast<const double2 *>(pv + s);
+                const double2 r2 = vel[0], r3 = vel[1]; // (vx,vy) (vz, -)
                 const float mass = __int_as_float((int)(__double_as_longlong(r1.y) & 0xffffffffLL));
-                const double hx = d_hat(d0), hy = d_hat(d1), hz = d_hat(d2);
+                // the kernel loop is bound by instruction issue: inside the support the hat function is 1 - |x|
+                // (1 + x for a negative x is the same IEEE operation as 1 - |x|), and the shifted argument
+                // x + 1/2 lies in [-1/2, 3/2], so only its upper cut-off needs a test
+                const double hx = d_hat_in(d0), hy = d_hat_in(d1), hz = d_hat_in(d2);
                 const double wgt = hx * hy * hz;
                 if (with_density && wgt > 0) {
                     const double add = (double)0.f + wgt * (double)mass / denom;
                     dens = (float)((double)dens + add);
                 }
                 const float x0 = (float)hx, y0 = (float)hy, z0 = (float)hz;
-                const float x1 = (float)d_hat(d0 + 0.5), y1 = (float)d_hat(d1 + 0.5), z1 = (float)d_hat(d2 + 0.5);
+                const float x1 = (float)d_hat_up(d0 + 0.5), y1 = (float)d_hat_up(d1 + 0.5), z1 = (float)d_hat_up(d2 + 0.5);
                 const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
                 if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
                     ws0 = ws0 + w0; ws1 = ws1 + w1; ws2 = ws2 + w2;
@@ -324,7 +336,7 @@ static int ensure_records(flip_ctx *ctx) {
     for (int q = 0; q < 6; ++q) ps.a[q] = ctx->p[ctx->cur][q];
     ps.mass = ctx->mass[ctx->cur];
     ps.pid = ctx->pid[ctx->cur];
-    k_pack_records<<<flip_grid_blocks(ctx->n), FLIP_BLOCK, 0, ctx->stream>>>(ctx->n, ps, ctx->prec);
+    k_pack_records<<<flip_grid_blocks(ctx->n), FLIP_BLOCK, 0, ctx->stream>>>(ctx->n, ps, packed_pos(ctx), packed_vel(ctx));
     FLIP_LAUNCH_CHECK();
     ctx->prec_valid = true;
     return 0;
@@ -339,8 +351,9 @@ extern "C" int flip_p2g(flip_ctx *ctx) {
     DensityArgs da{ ctx->phi_fluid, ctx->density, ctx->d_counts + 2, ctx->g.phi_fluid_bg, ctx->g.rest_density,
                     pow((double)ctx->g.dx, 3) };
     FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
-    k_p2g<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->cell_start, ctx->band, ctx->prec,
-                                                                   ctx->vel[1][0], ctx->vel[1][1], ctx->vel[1][2], ctx->active, da);
+    k_p2g<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->cell_start, ctx->band, packed_pos(ctx),
+                                                                   packed_vel(ctx), ctx->vel[1][0], ctx->vel[1][1], ctx->vel[1][2],
+                                                                   ctx->active, da);
     FLIP_LAUNCH_CHECK();
     ctx->density_valid = true;
     for (int a = 0; a < 3; ++a) std::swap(ctx->vel[0][a], ctx->vel[1][a]);
@@ -663,7 +676,7 @@ extern "C" int flip_advect_particles(flip_ctx *ctx, float dt) {
 // Density (src/FluidSimulator.cpp:625-652, src/Functors.cpp:216-266).
 
 __global__ void k_density(GridDims g, float phi_bg, float rest, double vs3, const int32_t *__restrict__ cell_start,
-                          const uint8_t *__restrict__ band, const float *__restrict__ phi, const flip_prec *__restrict__ prec,
+                          const uint8_t *__restrict__ band, const float *__restrict__ phi, const flip_ppos *__restrict__ prec,
                           float *__restrict__ density, int32_t *__restrict__ n_over) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.B) return;
@@ -690,8 +703,8 @@ __global__ void k_density(GridDims g, float phi_bg, float rest, double vs3, cons
                     const double2 r0 = rec[0];
                     const double rz = prec[s].z;
                     const double d0 = r0.x - cx, d1 = r0.y - cy, d2 = rz - cz;
-                    if (d0 < -1. || d0 > 1. || d1 < -1. || d1 > 1. || d2 < -1. || d2 > 1.) continue;
-                    const double wgt = d_hat(d0) * d_hat(d1) * d_hat(d2);
+                    if (fabs(d0) > 1. || fabs(d1) > 1. || fabs(d2) > 1.) continue;
+                    const double wgt = d_hat_in(d0) * d_hat_in(d1) * d_hat_in(d2);
                     if (wgt > 0) {
                         const double add = (double)0.f + wgt * (double)prec[s].mass / denom;
                         dens = (float)((double)dens + add);
@@ -715,7 +728,7 @@ extern "C" int flip_density(flip_ctx *ctx, int64_t *n_overdense) {
         FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
         k_density<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->g.phi_fluid_bg, ctx->g.rest_density,
                                                                            vs3, ctx->cell_start, ctx->band, ctx->phi_fluid,
-                                                                           ctx->prec, ctx->density, ctx->d_counts + 2);
+                                                                           packed_pos(ctx), ctx->density, ctx->d_counts + 2);
         FLIP_LAUNCH_CHECK();
         ctx->density_valid = true;
     }

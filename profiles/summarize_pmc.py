@@ -1,19 +1,28 @@
-"""Per-kernel mean of one rocprofv3 --pmc counter: python summarize_pmc.py <counter_collection.csv> <counter> [out.csv]"""
+"""Per-kernel mean of rocprofv3 --pmc counters.
+
+    python summarize_pmc.py <counter_collection.csv> <counter>[,<counter>...] [out.csv] [kernel-name filter]
+"""
 import csv
 import sys
 from collections import defaultdict
 
-path, counter = sys.argv[1], sys.argv[2]
-tot, cnt = defaultdict(float), defaultdict(int)
+path, counters = sys.argv[1], sys.argv[2].split(",")
+only = sys.argv[4] if len(sys.argv) > 4 else None
+tot = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(lambda: defaultdict(int))
 with open(path, newline="") as f:
     for row in csv.DictReader(f):
-        if row.get("Counter_Name") != counter:
+        c = row.get("Counter_Name")
+        if c not in counters:
             continue
         name = row["Kernel_Name"].split("(")[0]
-        tot[name] += float(row["Counter_Value"])
-        cnt[name] += 1
-rows = sorted(tot, key=lambda k: -tot[k])
-out = open(sys.argv[3], "w") if len(sys.argv) > 3 else sys.stdout
-out.write(f"kernel,launches,mean_{counter},total_{counter}\n")
+        if only and only not in name:
+            continue
+        tot[name][c] += float(row["Counter_Value"])
+        cnt[name][c] += 1
+rows = sorted(tot, key=lambda k: -tot[k][counters[0]])
+out = open(sys.argv[3], "w") if len(sys.argv) > 3 and sys.argv[3] != "-" else sys.stdout
+out.write("kernel,launches," + ",".join(f"mean_{c}" for c in counters) + "\n")
 for k in rows:
-    out.write(f"\"{k}\",{cnt[k]},{tot[k] / cnt[k]:.1f},{tot[k]:.1f}\n")
+    n = max(cnt[k][counters[0]], 1)
+    out.write(f"\"{k}\",{n}," + ",".join(f"{tot[k][c] / max(cnt[k][c], 1):.1f}" for c in counters) + "\n")
