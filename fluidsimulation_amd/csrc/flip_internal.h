@@ -142,6 +142,7 @@ struct flip_ctx {
     bool profiling = false;
     std::vector<hipEvent_t> events;
     std::vector<flip_mg_level> mg;  // coarse levels, finest first
+    float *mg_diag_f = nullptr, *mg_inv_f = nullptr; // float copies of cg_diag / cg_inv for the V-cycle's level 0 (one allocation)
 
     // ---- z-slab decomposition of the solve (flip_set_slab): rows of planes [slab_k0, slab_k1) belong to this
     // context, the other planes of the box are ghosts whose values a neighbouring rank supplies ----

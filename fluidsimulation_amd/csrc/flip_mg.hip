@@ -52,7 +52,8 @@ struct MgDev {
     const CT *cx, *cy, *cz;   // coupling toward the low x/y/z neighbour (0 = none)
     double scale;             // couplings are multiplied by this (dx^2 of the divergence system on level 0)
     double c1, a2, c2;        // smoother coefficients
-    const double *diag, *inv;
+    const CT *diag, *inv;     // diagonal and its inverse (0 off the rows); level 0 reads float copies: the
+                              // preconditioner does not need the last bits and these are a sixth of its traffic
     double *x, *b, *t;
     const int32_t *rows;
     const int32_t *n_rows;
@@ -66,7 +67,7 @@ __device__ __forceinline__ double d_mg_apply(const MgDev<CT> &L, long long c, co
     acc += (double)L.cy[c + L.sy] * v[c + L.sy];
     acc += (double)L.cz[c] * v[c - L.sz];
     acc += (double)L.cz[c + L.sz] * v[c + L.sz];
-    return L.diag[c] * v[c] - L.scale * acc;
+    return (double)L.diag[c] * v[c] - L.scale * acc;
 }
 
 // Pre-smoothing, both steps of the smoother from a zero guess in one kernel:
@@ -75,20 +76,21 @@ template <class CT>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_pre(MgDev<CT> L, const int32_t *done, double *__restrict__ out) {
     if (done && *done) return;
     const long long n = *L.n_rows;
-    const double *__restrict__ inv = L.inv, *__restrict__ b = L.b;
+    const CT *__restrict__ inv = L.inv;
+    const double *__restrict__ b = L.b;
 #pragma unroll 2
     for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
         const long long c = L.rows[q];
         const long long sy = L.sy, sz = L.sz;
-        const double bc = b[c], ic = inv[c];
+        const double bc = b[c], ic = (double)inv[c];
         const double t0 = L.c1 * ic * bc;
-        double acc = (double)L.cx[c] * (L.c1 * inv[c - 1] * b[c - 1]);
-        acc += (double)L.cx[c + 1] * (L.c1 * inv[c + 1] * b[c + 1]);
-        acc += (double)L.cy[c] * (L.c1 * inv[c - sy] * b[c - sy]);
-        acc += (double)L.cy[c + sy] * (L.c1 * inv[c + sy] * b[c + sy]);
-        acc += (double)L.cz[c] * (L.c1 * inv[c - sz] * b[c - sz]);
-        acc += (double)L.cz[c + sz] * (L.c1 * inv[c + sz] * b[c + sz]);
-        const double At = L.diag[c] * t0 - L.scale * acc;
+        double acc = (double)L.cx[c] * (L.c1 * (double)inv[c - 1] * b[c - 1]);
+        acc += (double)L.cx[c + 1] * (L.c1 * (double)inv[c + 1] * b[c + 1]);
+        acc += (double)L.cy[c] * (L.c1 * (double)inv[c - sy] * b[c - sy]);
+        acc += (double)L.cy[c + sy] * (L.c1 * (double)inv[c + sy] * b[c + sy]);
+        acc += (double)L.cz[c] * (L.c1 * (double)inv[c - sz] * b[c - sz]);
+        acc += (double)L.cz[c + sz] * (L.c1 * (double)inv[c + sz] * b[c + sz]);
+        const double At = (double)L.diag[c] * t0 - L.scale * acc;
         out[c] = t0 + L.a2 * t0 + L.c2 * ic * (bc - At);
     }
 }
@@ -104,7 +106,7 @@ __device__ __forceinline__ double d_mg_second_step(const MgDev<CT> &L, const MgD
     const int j = (int)(tq % L.ny), k = (int)(tq / L.ny);
     const double v0 = out[c] + C.x[(i >> 1) + C.sy * (j >> 1) + C.sz * (k >> 1)];
     const double x1 = in[c];
-    return x1 + L.a2 * (x1 - v0) + L.c2 * L.inv[c] * (b - d_mg_apply(L, c, in));
+    return x1 + L.a2 * (x1 - v0) + L.c2 * (double)L.inv[c] * (b - d_mg_apply(L, c, in));
 }
 template <class CT, bool RZ>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, MgDev<double> C, const int32_t *done,
@@ -165,8 +167,8 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post(MgDev<CT> F, MgDev<doubl
         acc += (double)F.cy[c + sy] * (in[c + sy] + xc[pyp]);
         acc += (double)F.cz[c] * (in[c - sz] + xc[pzm]);
         acc += (double)F.cz[c + sz] * (in[c + sz] + xc[pzp]);
-        const double Av = F.diag[c] * v0 - F.scale * acc;
-        out[c] = v0 + F.c1 * F.inv[c] * (F.b[c] - Av);
+        const double Av = (double)F.diag[c] * v0 - F.scale * acc;
+        out[c] = v0 + F.c1 * (double)F.inv[c] * (F.b[c] - Av);
     }
 }
 
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<d
             const int i = 2 * I + di, j = 2 * J + dj, k = 2 * K + dk;
             if (i < F.nx && j < F.ny && k < F.nz) {
                 const long long c = (long long)i + F.sy * j + F.sz * k;
-                if (F.inv[c] != 0.0) s = F.b[c] - d_mg_apply(F, c, v);
+                if (F.inv[c] != (CT)0) s = F.b[c] - d_mg_apply(F, c, v);
             }
         }
         s += __shfl_xor(s, 1, FLIP_WAVE);
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(1024) k_mg_coarsest(MgDev<double> L, const int
 
 // Galerkin coarsening with piecewise-constant transfer, scaled by 1/2 (see the header comment).
 template <class CT>
-__global__ void k_mg_coarsen(MgDev<CT> F, int cnx, int cny, int cnz, long long csy, long long csz, double *__restrict__ cx,
+__global__ void k_mg_coarsen(MgDev<CT> F, const double *__restrict__ fine_diag, int cnx, int cny, int cnz, long long csy, long long csz, double *__restrict__ cx,
                              double *__restrict__ cy, double *__restrict__ cz, double *__restrict__ diag,
                              double *__restrict__ inv, int32_t *__restrict__ mark) {
     const long long cB = (long long)cnx * cny * cnz;
@@ -289,7 +291,7 @@ __global__ void k_mg_coarsen(MgDev<CT> F, int cnx, int cny, int cnz, long long c
                 const int i = 2 * I + di, j = 2 * J + dj, k = 2 * K + dk;
                 if (i >= F.nx || j >= F.ny || k >= F.nz) continue;
                 const long long c = (long long)i + F.sy * j + F.sz * k;
-                sd += F.diag[c];
+                sd += fine_diag[c]; // the exact diagonal: a coarse cell is a row iff this balance is positive
                 const double ax = F.scale * (double)F.cx[c], ay = F.scale * (double)F.cy[c], az = F.scale * (double)F.cz[c];
                 if (di == 0) sx += ax; else internal += ax;   // low face of the coarse cell / face between two children
                 if (dj == 0) sy_ += ay; else internal += ay;
@@ -324,6 +326,14 @@ __global__ void k_mg_compact(long long B, const int32_t *__restrict__ scan, int3
     if (scan[c + 1] > scan[c]) rows[scan[c]] = (int32_t)c;
 }
 
+__global__ void k_mg_narrow(long long B, const double *__restrict__ diag, const double *__restrict__ inv, float *__restrict__ diag_f,
+                            float *__restrict__ inv_f) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    diag_f[c] = (float)diag[c];
+    inv_f[c] = (float)inv[c];
+}
+
 // ---------------------------------------------------------------------------------------------
 
 static hipError_t mg_alloc_padded(double **p, int64_t n, int64_t pad) {
@@ -335,6 +345,7 @@ static hipError_t mg_alloc_padded(double **p, int64_t n, int64_t pad) {
 }
 
 void flip_mg_free(flip_ctx *ctx) {
+    if (ctx->mg_diag_f) { (void)hipFree(ctx->mg_diag_f - ctx->pad); ctx->mg_diag_f = ctx->mg_inv_f = nullptr; }
     for (flip_mg_level &L : ctx->mg) {
         double **dp[] = { &L.cx, &L.cy, &L.cz, &L.diag, &L.inv, &L.x, &L.b, &L.t };
         for (double **q : dp)
@@ -389,7 +400,7 @@ static MgDev<float> mg_level0(flip_ctx *ctx) {
     L.cx = ctx->cg_c[0]; L.cy = ctx->cg_c[1]; L.cz = ctx->slab_on ? ctx->mg_cz : ctx->cg_c[2];
     L.scale = ctx->sys_s2;
     { const MgCheb k = mg_cheb(); L.c1 = k.c1; L.a2 = k.a2; L.c2 = k.c2; }
-    L.diag = ctx->cg_diag; L.inv = ctx->cg_inv;
+    L.diag = ctx->mg_diag_f; L.inv = ctx->mg_inv_f;
     L.x = ctx->z; L.b = ctx->r; L.t = ctx->ap;   // z = M^-1 r; Ap is free between the update and direction kernels
     L.rows = ctx->cg_rows; L.n_rows = ctx->d_counts + 6;
     return L;
@@ -408,10 +419,10 @@ static MgDev<double> mg_level(const flip_mg_level &S) {
 }
 
 template <class CT>
-static int mg_coarsen_into(flip_ctx *ctx, const MgDev<CT> &F, flip_mg_level &S) {
+static int mg_coarsen_into(flip_ctx *ctx, const MgDev<CT> &F, const double *fine_diag, flip_mg_level &S) {
     hipStream_t st = ctx->stream;
     const long long csy = S.nx, csz = (long long)S.nx * S.ny;
-    k_mg_coarsen<CT><<<flip_grid_blocks(S.B + 1), FLIP_BLOCK, 0, st>>>(F, S.nx, S.ny, S.nz, csy, csz, S.cx, S.cy, S.cz, S.diag,
+    k_mg_coarsen<CT><<<flip_grid_blocks(S.B + 1), FLIP_BLOCK, 0, st>>>(F, fine_diag, S.nx, S.ny, S.nz, csy, csz, S.cx, S.cy, S.cz, S.diag,
                                                                       S.inv, S.scan);
     FLIP_LAUNCH_CHECK();
     k_mg_prune<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.nx, S.ny, S.nz, csy, csz, S.inv, S.cx, S.cy, S.cz);
@@ -435,9 +446,19 @@ int flip_mg_setup(flip_ctx *ctx) {
         const flip_mg_level &S = ctx->mg.back();
         FLIP_REQUIRE(mg_coarsest_ok(S.nx, S.ny, S.nz), "multigrid: the coarsest level does not fit one workgroup");
     }
-    if (int rc = mg_coarsen_into(ctx, mg_level0(ctx), ctx->mg[0])) return rc;
+    // float copies of the level-0 diagonal and its inverse, padded like every array the stencil kernels read
+    if (!ctx->mg_diag_f) {
+        float *base = nullptr;
+        FLIP_CHECK(hipMalloc((void **)&base, 2 * (size_t)(ctx->B + 2 * ctx->pad) * sizeof(float)));
+        FLIP_CHECK(hipMemset(base, 0, 2 * (size_t)(ctx->B + 2 * ctx->pad) * sizeof(float)));
+        ctx->mg_diag_f = base + ctx->pad;
+        ctx->mg_inv_f = base + (ctx->B + 2 * ctx->pad) + ctx->pad;
+    }
+    k_mg_narrow<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(ctx->B, ctx->cg_diag, ctx->cg_inv, ctx->mg_diag_f, ctx->mg_inv_f);
+    FLIP_LAUNCH_CHECK();
+    if (int rc = mg_coarsen_into(ctx, mg_level0(ctx), ctx->cg_diag, ctx->mg[0])) return rc;
     for (size_t l = 1; l < ctx->mg.size(); ++l)
-        if (int rc = mg_coarsen_into(ctx, mg_level(ctx->mg[l - 1]), ctx->mg[l])) return rc;
+        if (int rc = mg_coarsen_into(ctx, mg_level(ctx->mg[l - 1]), ctx->mg[l - 1].diag, ctx->mg[l])) return rc;
     return 0;
 }
 
