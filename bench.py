@@ -143,9 +143,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    # rehearsal on a one-GPU box: FLIP_BENCH_REHEARSE=1 puts every rank on device 0 and uses gloo (RCCL refuses two
+    # ranks on one device); the communication layer then stages through the host.  Not a measurement.
+    rehearse = os.environ.get("FLIP_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from fluidsimulation_amd import FlipContext, FlipSubstep, PRECOND_JACOBI, PRECOND_MULTIGRID, scenes
     from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout
@@ -158,6 +166,11 @@ def main():
     else:
         sc = scenes.dam_break_slab(args.n, ppc=args.ppc, seed=12345)
         layout = SlabLayout(sc.dims[2], 1, 0)
+    # particles this rank owns (its ghost copies belong to the neighbours' counts)
+    o0, o1 = layout.owned(rank) if world > 1 and slabs else (0, sc.dims[2])
+    e0 = layout.extended(rank)[0] if world > 1 and slabs else 0
+    plane = np.floor(sc.pos[:, 2] + 0.5).astype(np.int64) - sc.origin[2] + e0
+    n_owned = int(((plane >= o0) & (plane < o1)).sum())
     ctx = FlipContext(sc.desc(), device=local)
     ctx.reserve_particles(sc.pos.shape[0] * 5 // 4 + 4096)
     ctx.upload_scene(sc)
@@ -184,11 +197,11 @@ def main():
     elapsed = time.perf_counter() - t0
     n_local = ctx.particle_count()
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        cnt = torch.tensor([float(sc.n_cells), float(n_local), float(infos[0]["divergence"]["cg_rows"])], dtype=torch.float64,
-                           device="cuda")
+        cnt = torch.tensor([float(sc.dims[0] * sc.dims[1] * (o1 - o0)), float(n_owned), float(infos[0]["divergence"]["cg_rows"])], dtype=torch.float64,
+                           device="cpu" if rehearse else "cuda")
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         tot_cells, tot_particles, tot_rows = (int(v) for v in cnt.tolist())
     else:

@@ -291,6 +291,9 @@ __global__ void k_mg_coarsen(MgDev<CT> F, const double *__restrict__ fine_diag, 
                 const int i = 2 * I + di, j = 2 * J + dj, k = 2 * K + dk;
                 if (i >= F.nx || j >= F.ny || k >= F.nz) continue;
                 const long long c = (long long)i + F.sy * j + F.sz * k;
+                // a child that is not a row contributes nothing; in slab mode the ghost cells are such children and,
+                // unlike every other non-row, still carry their x and y couplings
+                if (fine_diag[c] == 0.0) continue;
                 sd += fine_diag[c]; // the exact diagonal: a coarse cell is a row iff this balance is positive
                 const double ax = F.scale * (double)F.cx[c], ay = F.scale * (double)F.cy[c], az = F.scale * (double)F.cz[c];
                 if (di == 0) sx += ax; else internal += ax;   // low face of the coarse cell / face between two children

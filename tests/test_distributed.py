@@ -238,7 +238,7 @@ def test_two_rank_slab_solve_matches_the_global_solve(tmp_path):
 # ------------------------------------------------------------------------------------------------
 # GPU: two ranks on the one device of the box, real kernels, gloo with host staging
 
-def _gpu_worker(rank, port, out_dir, precond):
+def _gpu_worker(rank, port, out_dir, precond, kind):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -247,7 +247,7 @@ def _gpu_worker(rank, port, out_dir, precond):
     from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout, partition_scene
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=WORLD)
     try:
-        _gpu_rank_body(rank, out_dir, precond)
+        _gpu_rank_body(rank, out_dir, precond, kind)
     except BaseException:
         import traceback
         with open(os.path.join(out_dir, f"error_{rank}.txt"), "w") as f:
@@ -257,13 +257,13 @@ def _gpu_worker(rank, port, out_dir, precond):
         dist.destroy_process_group()
 
 
-def _gpu_rank_body(rank, out_dir, precond):
+def _gpu_rank_body(rank, out_dir, precond, kind):
     import torch
     from fluidsimulation_amd import FlipContext
     from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout, partition_scene
     if True:
         torch.cuda.set_device(0)
-        sc = _scene_gpu()
+        sc = _scene_gpu(kind)
         layout = SlabLayout(sc.dims[2], WORLD, 8)
         loc = partition_scene(sc, layout, rank)
         with FlipContext(loc.desc(), device=0) as ctx:
@@ -287,30 +287,34 @@ def _gpu_rank_body(rank, out_dir, precond):
                  * info2["divergence"]["converged"] * info2["density"]["converged"], p=p)
 
 
-def _scene_gpu():
+def _scene_gpu(kind="dam"):
     from fluidsimulation_amd import scenes
-    sc = scenes.dam_break(32, ppc=4, seed=9)
+    if kind == "long":
+        # the benchmark's multi-GPU scene: slab faces at odd planes, so coarse multigrid cells straddle them
+        sc = scenes.dam_break_slab(32, ppc=8, seed=12345, z_repeat=2)
+    else:
+        sc = scenes.dam_break(32, ppc=4, seed=9)
     rng = np.random.default_rng(2)
     sc.vel = rng.normal(0.0, 0.2, sc.pos.shape)
     return sc
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precond", [0, 1])
-def test_two_ranks_on_one_gpu_match_the_single_context_substep(tmp_path, precond):
+@pytest.mark.parametrize("precond,kind", [(0, "dam"), (1, "dam"), (1, "long")])
+def test_two_ranks_on_one_gpu_match_the_single_context_substep(tmp_path, precond, kind):
     import torch.multiprocessing as mp
     from fluidsimulation_amd import FlipContext, FlipSubstep
     from fluidsimulation_amd.distributed import SlabLayout
     port = _free_port()
     try:
-        mp.spawn(_gpu_worker, args=(port, str(tmp_path), precond), nprocs=WORLD, join=True)
+        mp.spawn(_gpu_worker, args=(port, str(tmp_path), precond, kind), nprocs=WORLD, join=True)
     except Exception:
         for r in range(WORLD):
             f = os.path.join(str(tmp_path), f"error_{r}.txt")
             if os.path.exists(f):
                 print(f"---- rank {r} ----\n" + open(f).read())
         raise
-    sc = _scene_gpu()
+    sc = _scene_gpu(kind)
     with FlipContext(sc.desc()) as ctx:
         ctx.upload_scene(sc)
         ref_info = FlipSubstep(ctx, precond=precond, max_iter=20000).step(0.004)
