@@ -369,6 +369,106 @@ extern "C" int flip_velocity_max(flip_ctx *ctx, double out_max[3]) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// constrain_velocity: src/FluidSimulator.cpp:1180-1247 (container) and :1249-1321 (rigid body).  On every face
+// whose solid fraction is exactly 1 the sampled velocity loses its component along the level set's normal (for
+// the body it takes the body's normal velocity instead).  Restates openvdb::tools::gradient (second-order central
+// differences scaled to world units, float), the BoxSampler on that Vec3f grid, Vec3::normalize (multiplies by
+// the reciprocal length, leaves a vector shorter than 1e-7 alone) and Vec3::projection (eps 1e-10 on the squared
+// length).  Reads the front buffer, writes the back buffer, then the buffers swap as in the reference.
+// The reference's call also switches on the voxels of the weight grids' topology in velFront; no output of the path
+// depends on that and it is not reproduced.
+
+struct ConstrainArgs {
+    GridDims g;
+    const float *phi;
+    float phi_bg, dx;
+    const float *wu, *wv, *ww;
+    const double *u, *v, *w;
+    double *ou, *ov, *ow;
+    int has_obj;
+    double vt[3], va[3];
+};
+__device__ __forceinline__ float d_lerpf_half(float a, float b) {
+    const double tmp = (double)(b - a) * 0.5;
+    return a + (float)tmp;
+}
+__device__ void d_level_set_gradient(const ConstrainArgs &A, int i, int j, int k, float out[3]) {
+    const double inv_dx = 1.0 / (double)A.dx;
+    const float dxp = (d_getf(A.g, A.phi, i + 1, j, k, A.phi_bg) - d_getf(A.g, A.phi, i - 1, j, k, A.phi_bg)) * 0.5f;
+    const float dyp = (d_getf(A.g, A.phi, i, j + 1, k, A.phi_bg) - d_getf(A.g, A.phi, i, j - 1, k, A.phi_bg)) * 0.5f;
+    const float dzp = (d_getf(A.g, A.phi, i, j, k + 1, A.phi_bg) - d_getf(A.g, A.phi, i, j, k - 1, A.phi_bg)) * 0.5f;
+    out[0] = (float)((double)dxp * inv_dx);
+    out[1] = (float)((double)dyp * inv_dx);
+    out[2] = (float)((double)dzp * inv_dx);
+}
+__device__ double d_constrained_component(const ConstrainArgs &A, int i, int j, int k, int axis) {
+    int lo[3] = { i, j, k };
+    lo[axis] -= 1;
+    float ga[3], gb[3], nrm[3];
+    d_level_set_gradient(A, lo[0], lo[1], lo[2], ga);
+    d_level_set_gradient(A, i, j, k, gb);
+    for (int a = 0; a < 3; ++a) nrm[a] = d_lerpf_half(ga[a], gb[a]);
+    if (!(nrm[0] == 0.f && nrm[1] == 0.f && nrm[2] == 0.f)) {
+        const float len = sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+        if (!(fabsf(len) <= 1e-7f)) {
+            const float r = 1.0f / len;
+            for (int a = 0; a < 3; ++a) nrm[a] = nrm[a] * r;
+        }
+    }
+    double p[3] = { (double)(A.g.ox + i), (double)(A.g.oy + j), (double)(A.g.oz + k) };
+    p[axis] -= 0.5;
+    const double vel[3] = { d_box_sample(A.g, A.u, p[0] + 0.5, p[1], p[2]), d_box_sample(A.g, A.v, p[0], p[1] + 0.5, p[2]),
+                            d_box_sample(A.g, A.w, p[0], p[1], p[2] + 0.5) };
+    const double n[3] = { (double)nrm[0], (double)nrm[1], (double)nrm[2] };
+    const double l = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    double proj = 0.0;
+    if (!(fabs(l) <= 1e-10)) proj = n[axis] * ((vel[0] * n[0] + vel[1] * n[1] + vel[2] * n[2]) * (1.0 / l));
+    double out = vel[axis] - proj;
+    if (A.has_obj) {
+        // solidVel = vel_trans + voxel * (vel_ang x (coord - e/2)), src/FluidSimulator.cpp:1287
+        const double vs = (double)A.dx;
+        const double c[3] = { vs * A.va[1] * p[2] - vs * A.va[2] * p[1], vs * A.va[2] * p[0] - vs * A.va[0] * p[2],
+                              vs * A.va[0] * p[1] - vs * A.va[1] * p[0] };
+        const double sv[3] = { A.vt[0] + c[0], A.vt[1] + c[1], A.vt[2] + c[2] };
+        out = out + (n[0] * sv[0] + n[1] * sv[1] + n[2] * sv[2]) * n[axis];
+    }
+    return out;
+}
+__global__ void k_constrain(ConstrainArgs A) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= A.g.B) return;
+    int i, j, k;
+    d_ijk(A.g, c, i, j, k);
+    A.ou[c] = A.wu[c] == 1.f ? d_constrained_component(A, i, j, k, 0) : A.u[c];
+    A.ov[c] = A.wv[c] == 1.f ? d_constrained_component(A, i, j, k, 1) : A.v[c];
+    A.ow[c] = A.ww[c] == 1.f ? d_constrained_component(A, i, j, k, 2) : A.w[c];
+}
+
+extern "C" int flip_constrain_velocity(flip_ctx *ctx, int rigid_body) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(!rigid_body || ctx->has_obj, "flip_constrain_velocity: no rigid body attached");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    ConstrainArgs A;
+    A.g = flip_dims(ctx);
+    A.dx = ctx->g.dx;
+    A.has_obj = rigid_body ? 1 : 0;
+    if (rigid_body) {
+        A.phi = ctx->phi_obj; A.phi_bg = ctx->phi_obj_bg;
+        A.wu = ctx->owgt[0]; A.wv = ctx->owgt[1]; A.ww = ctx->owgt[2];
+    } else {
+        A.phi = ctx->phi_solid; A.phi_bg = ctx->g.phi_solid_bg;
+        A.wu = ctx->wgt[0]; A.wv = ctx->wgt[1]; A.ww = ctx->wgt[2];
+    }
+    A.u = ctx->vel[0][0]; A.v = ctx->vel[0][1]; A.w = ctx->vel[0][2];
+    A.ou = ctx->vel[1][0]; A.ov = ctx->vel[1][1]; A.ow = ctx->vel[1][2];
+    for (int a = 0; a < 3; ++a) { A.vt[a] = ctx->obj_vel[a]; A.va[a] = ctx->obj_vel[3 + a]; }
+    k_constrain<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(A);
+    FLIP_LAUNCH_CHECK();
+    for (int a = 0; a < 3; ++a) std::swap(ctx->vel[0][a], ctx->vel[1][a]);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Projections (src/FluidSimulator.cpp:1017-1102 and :1104-1178): every cell of the box; pressure
 // narrowed to float and the gradient evaluated in float, as the reference does.
 

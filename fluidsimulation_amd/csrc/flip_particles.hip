@@ -364,31 +364,6 @@ extern "C" int flip_p2g(flip_ctx *ctx) {
 // Staggered trilinear sampling (OpenVDB StaggeredBoxSampler as used by MacGrid::StaggeredSampler,
 // headers/MacGrid.h:36-37): component c at pos + e_c/2; z, then y, then x; each step a + (b-a)*t.
 
-__device__ __forceinline__ double d_lerp(double a, double b, double t) {
-    const double tmp = (b - a) * t;
-    return a + tmp;
-}
-__device__ __forceinline__ double d_box_sample(const GridDims &g, const double *__restrict__ f, double x, double y, double z) {
-    const double fx = floor(x), fy = floor(y), fz = floor(z);
-    const int i = (int)fx - g.ox, j = (int)fy - g.oy, k = (int)fz - g.oz;
-    const double tu = x - fx, tv = y - fy, tw = z - fz;
-    double d000, d001, d010, d011, d100, d101, d110, d111;
-    if (i >= 0 && j >= 0 && k >= 0 && i + 1 < g.nx && j + 1 < g.ny && k + 1 < g.nz) {
-        const long long c = d_lid(g, i, j, k), sy = g.nx, sz = (long long)g.nx * g.ny;
-        d000 = f[c]; d100 = f[c + 1];
-        d010 = f[c + sy]; d110 = f[c + sy + 1];
-        d001 = f[c + sz]; d101 = f[c + sz + 1];
-        d011 = f[c + sz + sy]; d111 = f[c + sz + sy + 1];
-    } else {
-        d000 = d_getd(g, f, i, j, k); d100 = d_getd(g, f, i + 1, j, k);
-        d010 = d_getd(g, f, i, j + 1, k); d110 = d_getd(g, f, i + 1, j + 1, k);
-        d001 = d_getd(g, f, i, j, k + 1); d101 = d_getd(g, f, i + 1, j, k + 1);
-        d011 = d_getd(g, f, i, j + 1, k + 1); d111 = d_getd(g, f, i + 1, j + 1, k + 1);
-    }
-    return d_lerp(d_lerp(d_lerp(d000, d001, tw), d_lerp(d010, d011, tw), tv),
-                  d_lerp(d_lerp(d100, d101, tw), d_lerp(d110, d111, tw), tv), tu);
-}
-
 __global__ void k_g2p(GridDims g, long long n, const double *__restrict__ px, const double *__restrict__ py,
                       const double *__restrict__ pz, double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
                       const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,

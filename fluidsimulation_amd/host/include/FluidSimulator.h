@@ -31,6 +31,7 @@ public:
     int preconditioner = FLIP_PRECOND_MULTIGRID;
     bool density_constraint = true;    // DENSITY_CONSTRAINT_PPE
     bool advect = true;                // FluidDomain::advectParticles inside the substep
+    bool constrain = true;             // the two constrain_velocity calls of the substep
     bool verbose = true;               // the reference prints per-substep timings
     int substeps_taken = 0;
     FlipSolveReport last_divergence_solve, last_density_solve;
@@ -40,6 +41,8 @@ private:
     void transfer_from_particles_to_grid(FluidDomain &domain);
     void add_forces(FluidDomain &domain, float dt);
     void extrapolate_data(FluidDomain &domain, int iterations_n);
+    void constrain_velocity(FluidDomain &domain);
+    void constrain_velocity(FluidDomain &domain, SolidObject &solidObject);
     void prepare_pressure_solve(FluidDomain &domain);
     void solve_pressure_divirgence(FluidDomain &domain, float dt);
     void solve_pressure_density(FluidDomain &domain, float dt);

@@ -55,13 +55,16 @@ void FluidSimulator::advance_flip_pic(FluidDomain &domain, float t_frame, float 
         transfer_from_particles_to_grid(domain);
         dev.check(flip_mark_valid_from_active(dev.ctx()), "flip_mark_valid_from_active"); // :343-345
         extrapolate_data(domain, 2);
-        // constrain_velocity (:357-361) is not on the device yet: the boundary faces keep their extrapolated values
+        constrain_velocity(domain);
+        if (!domain.solidObjs().empty()) constrain_velocity(domain, *domain.solidObjs()[0]);
         domain.grid().updatePreviousVelocityBuffer();
         add_forces(domain, timestep);
         prepare_pressure_solve(domain);
         solve_pressure_divirgence(domain, timestep);
         if (density_constraint) solve_pressure_density(domain, timestep);
         extrapolate_data(domain, 2);
+        constrain_velocity(domain);
+        if (!domain.solidObjs().empty()) constrain_velocity(domain, *domain.solidObjs()[0]);
         domain.grid().updateDiffBuffers();
         transfer_from_grid_to_particles(domain, flip_pic_ratio);
         if (advect) domain.advectParticles(timestep);
@@ -110,6 +113,18 @@ void FluidSimulator::add_forces(FluidDomain &domain, float dt) {
 void FluidSimulator::extrapolate_data(FluidDomain &domain, int iterations_n) {
     FlipDevice &dev = domain.device();
     dev.check(flip_extrapolate(dev.ctx(), iterations_n), "flip_extrapolate");
+}
+
+// src/FluidSimulator.cpp:1180-1247 and :1249-1321 (the body's state is the one the device already holds)
+void FluidSimulator::constrain_velocity(FluidDomain &domain) {
+    if (!constrain) return;
+    FlipDevice &dev = domain.device();
+    dev.check(flip_constrain_velocity(dev.ctx(), 0), "flip_constrain_velocity");
+}
+void FluidSimulator::constrain_velocity(FluidDomain &domain, SolidObject &) {
+    if (!constrain) return;
+    FlipDevice &dev = domain.device();
+    dev.check(flip_constrain_velocity(dev.ctx(), 1), "flip_constrain_velocity");
 }
 
 // src/FluidSimulator.cpp:482-492

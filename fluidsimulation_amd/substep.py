@@ -1,9 +1,10 @@
 """The hot-path part of one FLIP substep as a sequence of C-ABI calls.
 
 Mirrors the order of FluidSimulator::advance_flip_pic (src/FluidSimulator.cpp:307-446) for the stages
-that are on the device.  Stages that still belong to the host in the reference's design (fluid sources,
-level set from particles, solid constraint, RK3 advection) are not part of it: the level sets are
-inputs, and the particles move only by the density-projection displacements.
+that are on the device.  Fluid sources and the level set from particles are not part of it: the level sets
+are inputs.  `constrain=True` adds the two constrain_velocity calls (:357-361, :404-408) and `advect=True` the
+RK3 particle advection (:426); both default to off, which is the configuration the benchmark and the parity tests'
+reference substep use (the particles then move only by the density-projection displacements).
 """
 from __future__ import annotations
 
@@ -12,14 +13,22 @@ from .binding import FlipContext, PRECOND_JACOBI, SOLVE_DENSITY, SOLVE_DIVERGENC
 
 class FlipSubstep:
     def __init__(self, ctx: FlipContext, flip_pic_ratio: float = 0.95, tol: float = 1e-15, max_iter: int = 0,
-                 precond: int = PRECOND_JACOBI, density_projection: bool = True):
+                 precond: int = PRECOND_JACOBI, density_projection: bool = True, constrain: bool = False,
+                 advect: bool = False, rigid_body: bool = False):
         self.ctx = ctx
         self.ratio = flip_pic_ratio      # main.cpp:167
         self.tol = tol                   # src/FluidSimulator.cpp:660
         self.max_iter = max_iter
         self.precond = precond
         self.density_projection = density_projection   # DENSITY_CONSTRAINT_PPE, src/FluidSimulator.cpp:31
+        self.constrain, self.advect, self.rigid_body = constrain, advect, rigid_body
         self.info = {}
+
+    def _constrain(self):
+        if self.constrain:
+            self.ctx.constrain_velocity(False)    # :357 / :404
+            if self.rigid_body:
+                self.ctx.constrain_velocity(True) # :358-361 / :405-408
 
     def step(self, dt: float) -> dict:
         c = self.ctx
@@ -27,6 +36,7 @@ class FlipSubstep:
         c.p2g()                                   # :337
         c.mark_valid_from_active()                # :343-345
         c.extrapolate(2)                          # :349
+        self._constrain()
         c.update_prev()                           # :367
         c.add_forces(dt)                          # :373
         c.index_cells()                           # :486  (weights of the previous substep)
@@ -41,8 +51,11 @@ class FlipSubstep:
             info_den = c.pcg_solve(self.tol, self.max_iter, self.precond)
             c.project_displacement(dt)            # :523
         c.extrapolate(2)                          # :398
+        self._constrain()
         c.update_diff()                           # :416
         c.g2p(self.ratio)                         # :420
+        if self.advect:
+            c.advect_particles(dt)                # :426
         if self.density_projection:
             c.apply_displacements()               # :429
         self.info = {"divergence": info_div, "density": info_den}

@@ -165,6 +165,10 @@ int flip_advect_particles(flip_ctx *ctx, float dt);
 int flip_mark_valid_from_active(flip_ctx *ctx);
 /* FluidSimulator::extrapolate_data (src/FluidSimulator.cpp:181-265). */
 int flip_extrapolate(flip_ctx *ctx, int iterations);
+/* FluidSimulator::constrain_velocity (src/FluidSimulator.cpp:1180-1247; rigid_body != 0: the overload for the
+ * attached SolidObject, :1249-1321, with the velocity last given to flip_solid_object_set or updated by
+ * flip_project_velocity).  Uses the face fractions currently stored, as the reference does. */
+int flip_constrain_velocity(flip_ctx *ctx, int rigid_body);
 /* FluidSimulator::add_forces, fluid part (src/FluidSimulator.cpp:460-473). */
 int flip_add_forces(flip_ctx *ctx, float dt);
 /* MacGrid::updatePreviousVelocityBuffer / updateDiffBuffers (src/MacGrid.cpp:55-63). */

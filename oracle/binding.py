@@ -104,6 +104,8 @@ class Oracle:
         L.orc_update_diff.argtypes = [i64, vp, vp, vp]
         L.orc_extrapolate_sweep.argtypes = [G, vp, vp, vp, vp]
         L.orc_add_gravity.argtypes = [i64, vp, vp, f32, f32]
+        L.orc_constrain_velocity.argtypes = [G, vp, f32] + [vp] * 9 + [C.c_int, vp, vp]
+        L.orc_constrain_velocity.restype = None
         L.orc_set_num_threads(threads)
 
     # ---- helpers ----
@@ -315,11 +317,26 @@ class Oracle:
         self.lib.orc_add_gravity(self.B, _ptr(active), _ptr(out), np.float32(grav), np.float32(dt))
         return out
 
+    def constrain_velocity(self, phi, bg, w, uvw, obj_vel=None):
+        """src/FluidSimulator.cpp:1180-1321: faces with solid fraction 1 lose the normal component (obj_vel: the
+        rigid body's 6-vector for the overload that adds the body's normal velocity)."""
+        out = [self._f64() for _ in range(3)]
+        vt = va = None
+        if obj_vel is not None:
+            ov = np.ascontiguousarray(obj_vel, dtype=np.float64)
+            vt, va = np.ascontiguousarray(ov[:3]), np.ascontiguousarray(ov[3:])
+        self.lib.orc_constrain_velocity(C.byref(self.g), _ptr(np.ascontiguousarray(phi, np.float32)), np.float32(bg),
+                                        _ptr(w[0]), _ptr(w[1]), _ptr(w[2]), _ptr(uvw[0]), _ptr(uvw[1]), _ptr(uvw[2]),
+                                        _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), 0 if obj_vel is None else 1, _ptr(vt), _ptr(va))
+        return out
+
     # ---- one substep, the same stage order as fluidsimulation_amd.substep.FlipSubstep ----
     def substep(self, st: dict, dt: float, ratio: float = 0.95, tol: float = 1e-15, density_projection: bool = True,
-                max_iter: int = 0, drop_null_rows: bool = True, eliminate: bool = True) -> dict:
+                max_iter: int = 0, drop_null_rows: bool = True, eliminate: bool = True, constrain: bool = False) -> dict:
         """st holds: pos, vel, mass, phi_fluid, phi_solid, w (3 stale weights), valid (3), and optionally
-        obj = dict(phi, bg, com, minv, vel).  Returns a dict with every intermediate field."""
+        obj = dict(phi, bg, com, minv, vel) and ow (the body's stale weights).  constrain: also the two
+        constrain_velocity calls of src/FluidSimulator.cpp:357-361 and :404-408.  Returns a dict with every
+        intermediate field."""
         out = {}
         pos, vel, mass = st["pos"], st["vel"], st["mass"]
         phi_f, phi_s = st["phi_fluid"], st["phi_solid"]
@@ -334,6 +351,11 @@ class Oracle:
         valid = [np.maximum(v, active) for v in st["valid"]]
         uvw, valid, active = self.extrapolate(uvw, valid, active, 2)
         out["extrap1"] = [a.copy() for a in uvw]
+        if constrain:   # with the face fractions of the previous substep, as the reference's call order has it
+            uvw = self.constrain_velocity(phi_s, self.g.phi_solid_bg, st["w"], uvw)
+            if st.get("obj") is not None and st.get("ow") is not None:
+                uvw = self.constrain_velocity(st["obj"]["phi"], st["obj"]["bg"], st["ow"], uvw, st["obj"]["vel"])
+            out["constrained1"] = [a.copy() for a in uvw]
         prev = [a.copy() for a in uvw]
         uvw = [uvw[0], self.add_gravity(uvw[1], active, dt), uvw[2]]
         out["pre_project"] = [a.copy() for a in uvw]
@@ -381,6 +403,10 @@ class Oracle:
             disp = self.project_displacement(dt, index, p2, phi_f, w)
             out["disp"] = disp
         uvw, valid, active = self.extrapolate(uvw, valid, active, 2)
+        if constrain:
+            uvw = self.constrain_velocity(phi_s, self.g.phi_solid_bg, w, uvw)
+            if obj is not None:
+                uvw = self.constrain_velocity(obj["phi"], obj["bg"], ow, uvw, out["obj_vel"])
         out["final_vel"] = uvw
         diff = self.update_diff(uvw, prev)
         out["diff"] = diff

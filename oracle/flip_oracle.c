@@ -1126,3 +1126,71 @@ ORC_EXPORT void orc_add_gravity(int64_t B, const uint8_t *active, double *v, flo
     for (int64_t c = 0; c < B; ++c)
         if (active[c]) v[c] = v[c] - (double)(grav * dt);
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* constrain_velocity: src/FluidSimulator.cpp:1180-1247 (container) and :1249-1321 (rigid  */
+/* body).  On every face whose solid fraction is exactly 1 the sampled velocity loses its  */
+/* component along the level set's normal (and, for the body, takes the body's normal      */
+/* velocity instead).  Restates openvdb::tools::gradient (second-order central differences */
+/* scaled to world units, float), BoxSampler on the Vec3f gradient, Vec3::normalize (multi- */
+/* plies by the reciprocal length, leaves a vector shorter than 1e-7 alone) and            */
+/* Vec3::projection (eps 1e-10 on the squared length): OpenVDB internals, parity unpinned. */
+/* Reads (u,v,w), writes (ou,ov,ow); every other face is copied.                            */
+static void level_set_gradient(const orc_grid *g, const float *phi, float bg, int i, int j, int k, float out[3]) {
+    const double inv_dx = 1.0 / (double)g->dx;
+    const float dxp = (getf(g, phi, i + 1, j, k, bg) - getf(g, phi, i - 1, j, k, bg)) * 0.5f;
+    const float dyp = (getf(g, phi, i, j + 1, k, bg) - getf(g, phi, i, j - 1, k, bg)) * 0.5f;
+    const float dzp = (getf(g, phi, i, j, k + 1, bg) - getf(g, phi, i, j, k - 1, bg)) * 0.5f;
+    out[0] = (float)((double)dxp * inv_dx);
+    out[1] = (float)((double)dyp * inv_dx);
+    out[2] = (float)((double)dzp * inv_dx);
+}
+static double constrained_component(const orc_grid *g, const float *phi, float bg, const double *u, const double *v,
+                                    const double *w, int i, int j, int k, int axis, int has_obj, const double *vt,
+                                    const double *va) {
+    /* face position: cell centre minus half a voxel along the axis */
+    int lo[3] = { i, j, k };
+    lo[axis] -= 1;
+    float ga[3], gb[3], nrm[3];
+    level_set_gradient(g, phi, bg, lo[0], lo[1], lo[2], ga);
+    level_set_gradient(g, phi, bg, i, j, k, gb);
+    for (int a = 0; a < 3; ++a) nrm[a] = lerp_f(ga[a], gb[a], 0.5);
+    if (!(nrm[0] == 0.f && nrm[1] == 0.f && nrm[2] == 0.f)) {
+        const float len = sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+        if (!(fabsf(len) <= 1e-7f)) {
+            const float r = 1.0f / len;
+            for (int a = 0; a < 3; ++a) nrm[a] = nrm[a] * r;
+        }
+    }
+    double p[3] = { (double)(g->ox + i), (double)(g->oy + j), (double)(g->oz + k) };
+    p[axis] -= 0.5;
+    double vel[3];
+    staggered_sample(g, u, v, w, p, vel);
+    const double n[3] = { (double)nrm[0], (double)nrm[1], (double)nrm[2] };
+    const double l = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    double proj = 0.0;
+    if (!(fabs(l) <= 1e-10)) proj = n[axis] * ((vel[0] * n[0] + vel[1] * n[1] + vel[2] * n[2]) * (1.0 / l));
+    double out = vel[axis] - proj;
+    if (has_obj) {
+        /* solidVel = vel_trans + voxel * (vel_ang x (coord - e/2)), src/FluidSimulator.cpp:1287 */
+        const double vs = (double)g->dx;
+        const double c[3] = { vs * va[1] * p[2] - vs * va[2] * p[1], vs * va[2] * p[0] - vs * va[0] * p[2],
+                              vs * va[0] * p[1] - vs * va[1] * p[0] };
+        const double sv[3] = { vt[0] + c[0], vt[1] + c[1], vt[2] + c[2] };
+        out = out + (n[0] * sv[0] + n[1] * sv[1] + n[2] * sv[2]) * n[axis];
+    }
+    return out;
+}
+ORC_EXPORT void orc_constrain_velocity(const orc_grid *g, const float *phi, float phi_bg, const float *wu, const float *wv,
+                                       const float *ww, const double *u, const double *v, const double *w, double *ou,
+                                       double *ov, double *ow, int has_obj, const double *vel_trans, const double *vel_ang) {
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < g->nz; ++k)
+        for (int j = 0; j < g->ny; ++j)
+            for (int i = 0; i < g->nx; ++i) {
+                const int64_t c = lid(g, i, j, k);
+                ou[c] = wu[c] == 1.f ? constrained_component(g, phi, phi_bg, u, v, w, i, j, k, 0, has_obj, vel_trans, vel_ang) : u[c];
+                ov[c] = wv[c] == 1.f ? constrained_component(g, phi, phi_bg, u, v, w, i, j, k, 1, has_obj, vel_trans, vel_ang) : v[c];
+                ow[c] = ww[c] == 1.f ? constrained_component(g, phi, phi_bg, u, v, w, i, j, k, 2, has_obj, vel_trans, vel_ang) : w[c];
+            }
+}

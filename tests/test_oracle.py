@@ -284,3 +284,33 @@ def test_elimination_solves_the_same_system_as_the_as_run_iteration():
     null = A.diagonal() == 0
     res = (A @ b["p_div"] - rb)[~null]
     assert np.linalg.norm(res) <= 1e-13 * np.linalg.norm(rb[~null])
+
+
+def test_constrain_velocity_removes_the_wall_normal_component():
+    """Analytic check of the constrain_velocity restatement (src/FluidSimulator.cpp:1180-1247): well inside the
+    floor of the container the level set's gradient is +y, so a fully solid v-face ends with zero velocity and
+    fully solid u- and w-faces keep theirs; faces that are not fully solid are untouched."""
+    from fluidsimulation_amd import scenes
+    from oracle import Oracle
+    sc = scenes.cube_drop(16, ppc=2, seed=3)
+    o = Oracle(sc.desc())
+    wm = o.weight_mask(sc.phi_fluid, sc.phi_fluid_bg)
+    w = o.face_fractions(sc.phi_solid, sc.phi_solid_bg, wm)
+    o.combine_weights(w, None)
+    uvw = [np.full(o.shape, 0.7), np.full(o.shape, -0.4), np.full(o.shape, 0.2)]
+    out = o.constrain_velocity(sc.phi_solid, sc.phi_solid_bg, w, uvw)
+    ox, oy, oz = sc.origin
+    lo, hi = np.asarray(sc.box_lo), np.asarray(sc.box_hi)
+    touched = 0
+    for k, j, i in np.argwhere(w[1] == 1):
+        x, y, z = ox + i, oy + j, oz + k
+        if lo[0] + 2 < x < hi[0] - 2 and lo[2] + 2 < z < hi[2] - 2 and y - 0.5 < lo[1] - 1:   # under the floor, away from edges
+            assert abs(out[1][k, j, i]) < 1e-12
+            touched += 1
+    assert touched >= 5      # the weight grids only cover the neighbourhood of the fluid
+    for a in range(3):
+        assert np.array_equal(out[a][w[a] != 1], uvw[a][w[a] != 1])
+    for k, j, i in np.argwhere(w[0] == 1)[:200]:
+        x, y, z = ox + i, oy + j, oz + k
+        if lo[0] + 2 < x < hi[0] - 2 and lo[2] + 2 < z < hi[2] - 2 and y < lo[1] - 1:
+            assert abs(out[0][k, j, i] - 0.7) < 1e-12
