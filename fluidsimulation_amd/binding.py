@@ -59,7 +59,7 @@ EXPORTS = [
     "flip_ctx_create", "flip_ctx_destroy", "flip_last_error", "flip_synchronize", "flip_get_desc",
     "flip_particles_upload", "flip_particles_download", "flip_particles_count", "flip_bin_particles",
     "flip_binning_download", "flip_field_upload", "flip_field_download", "flip_field_bytes", "flip_p2g", "flip_g2p",
-    "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
+    "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_fluid_levelset_from_particles", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
     "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
     "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_project_velocity",
@@ -101,6 +101,7 @@ def load_library(path: str = LIB_PATH):
         "flip_apply_displacements": (C.c_int, [vp]),
         "flip_advect_particles": (C.c_int, [vp, C.c_float]),
         "flip_constrain_velocity": (C.c_int, [vp, C.c_int]),
+        "flip_fluid_levelset_from_particles": (C.c_int, [vp, C.c_float, C.c_float]),
         "flip_mark_valid_from_active": (C.c_int, [vp]),
         "flip_extrapolate": (C.c_int, [vp, C.c_int]),
         "flip_add_forces": (C.c_int, [vp, f32]),
@@ -233,6 +234,9 @@ class FlipContext:
 
     def advect_particles(self, dt):
         self._check(self.lib.flip_advect_particles(self.h, float(dt)))
+
+    def fluid_levelset_from_particles(self, radius_world: float, half_width_voxels: float = 3.0):
+        self._check(self.lib.flip_fluid_levelset_from_particles(self.h, float(radius_world), float(half_width_voxels)))
 
     def constrain_velocity(self, rigid_body: bool = False):
         self._check(self.lib.flip_constrain_velocity(self.h, 1 if rigid_body else 0))

@@ -160,6 +160,16 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
     const GridDims g = flip_dims(ctx);
     const int64_t n = ctx->n, B = ctx->B;
     hipStream_t st = ctx->stream;
+    if (ctx->binned) { // nothing moved since the last sort
+        if (n_outside) {
+            int32_t ends[2];
+            FLIP_CHECK(hipMemcpyAsync(ends, ctx->cell_start + B, 8, hipMemcpyDeviceToHost, st));
+            FLIP_CHECK(hipStreamSynchronize(st));
+            ctx->n_outside = (int64_t)ends[1] - ends[0];
+            *n_outside = ctx->n_outside;
+        }
+        return 0;
+    }
     FLIP_CHECK(hipMemsetAsync(ctx->cell_start, 0, (size_t)(B + 2) * 4, st));
     FLIP_CHECK(hipMemsetAsync(ctx->cell_fill, 0, (size_t)(B + 1) * 4, st));
     const int src = ctx->cur, dst = 1 - src;
@@ -560,6 +570,81 @@ extern "C" int flip_particles_exchange_apply(flip_ctx *ctx, const void *recv_lo,
     ctx->binned = false;
     ctx->slots_valid = false;
     ctx->prec_valid = false;
+    ctx->density_valid = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fluid level set from the marker particles (src/FluidDomain.cpp:50-61, src/LevelSet.cpp:17-23): the union of the
+// particles' balls, phi(c) = min_p |c - p| - radius, clipped to the narrow band, then merged with the solid so that
+// the surface continues into the wall (IntersectSolidFluidLevelSets, headers/LevelSet.h:83-96).  The reference
+// rasterises with OpenVDB's ParticlesToLevelSet (parity unpinned); this is the exact distance to the nearest ball.
+// One thread per cell searches the sorted particles shell by shell (Chebyshev distance s = 0, 1, ... in cells): a
+// particle of shell s is at least s - 1/2 away, so the search stops as soon as the best distance found cannot be
+// beaten by the next shell, and a cell with no particle within reach keeps the background value.
+
+__device__ __forceinline__ void d_ls_range(const flip_ppos *__restrict__ pm, int32_t s0, int32_t s1, double cx, double cy,
+                                           double cz, double &best2) {
+    for (int32_t s = s0; s < s1; ++s) {
+        const double2 *rec = reinterpret_cast<const double2 *>(pm + s);
+        const double2 r0 = rec[0];
+        const double rz = rec[1].x;
+        const double dx = cx - r0.x, dy = cy - r0.y, dz = cz - rz;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        best2 = d2 < best2 ? d2 : best2;
+    }
+}
+__global__ void k_fluid_levelset(GridDims g, float vs, double radius, double half_width, int reach,
+                                 const int32_t *__restrict__ cell_start, const flip_ppos *__restrict__ pm,
+                                 const float *__restrict__ phi_solid, float *__restrict__ phi_fluid) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.B) return;
+    int i, j, k;
+    d_ijk(g, c, i, j, k);
+    const double cx = (double)(g.ox + i), cy = (double)(g.oy + j), cz = (double)(g.oz + k);
+    double best2 = 1e300;
+    for (int s = 0; s <= reach; ++s) {
+        for (int dz = -s; dz <= s; ++dz) {
+            const int kk = k + dz;
+            if (kk < 0 || kk >= g.nz) continue;
+            for (int dy = -s; dy <= s; ++dy) {
+                const int jj = j + dy;
+                if (jj < 0 || jj >= g.ny) continue;
+                const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
+                const bool face = dz == -s || dz == s || dy == -s || dy == s; // the whole x run lies on the shell
+                if (face) {
+                    const int xa = i - s > 0 ? i - s : 0, xb = i + s < g.nx - 1 ? i + s : g.nx - 1;
+                    d_ls_range(pm, cell_start[row + xa], cell_start[row + xb + 1], cx, cy, cz, best2);
+                } else {
+                    if (i - s >= 0) d_ls_range(pm, cell_start[row + i - s], cell_start[row + i - s + 1], cx, cy, cz, best2);
+                    if (i + s < g.nx) d_ls_range(pm, cell_start[row + i + s], cell_start[row + i + s + 1], cx, cy, cz, best2);
+                }
+            }
+        }
+        // every particle of a later shell is at least s + 1/2 away
+        if (best2 <= ((double)s + 0.5) * ((double)s + 0.5)) break;
+    }
+    double d = half_width;
+    if (best2 < 1e299) d = sqrt(best2) - radius;
+    d = d < -half_width ? -half_width : (d > half_width ? half_width : d);
+    float f = (float)(d * (double)vs);
+    const float ps = phi_solid[c];
+    if (ps <= 0) f = f > -ps ? f : -ps;
+    phi_fluid[c] = f;
+}
+
+extern "C" int flip_fluid_levelset_from_particles(flip_ctx *ctx, float radius_world, float half_width_voxels) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(radius_world > 0.f && half_width_voxels > 0.f, "flip_fluid_levelset_from_particles: bad radius or band");
+    FLIP_REQUIRE(ctx->binned, "flip_fluid_levelset_from_particles: call flip_bin_particles first");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    if (int rc = ensure_records(ctx)) return rc;
+    const double radius = (double)radius_world / (double)ctx->g.dx; // index units
+    const int reach = (int)ceil(radius + (double)half_width_voxels);
+    k_fluid_levelset<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->g.dx, radius,
+                                                                              (double)half_width_voxels, reach, ctx->cell_start,
+                                                                              packed_pos(ctx), ctx->phi_solid, ctx->phi_fluid);
+    FLIP_LAUNCH_CHECK();
     ctx->density_valid = false;
     return 0;
 }

@@ -36,7 +36,8 @@ public:
     void constructFluidLevelSetFromMarkerParticles();
 
     inline MacGrid &grid() { return _grid; };
-    inline LevelSet &fluidLevelSet() { return _fluid_level_set; };
+    // the level set is built on the device; the host grid is refreshed from it when someone asks for it
+    LevelSet &fluidLevelSet();
     inline LevelSet &solidLevelSet() { return _solid_level_set; };
     inline std::vector<std::shared_ptr<SolidObject>> &solidObjs() { return _solid_objs; }
     inline ParticleSet &particleSet() { return particle_set; };
@@ -70,4 +71,5 @@ private:
     unsigned _solid_version_on_device = 0;
     unsigned _fluid_version_on_device = 0;
     bool _object_on_device = false;
+    bool _fluid_device_newer = false;
 };

@@ -48,12 +48,13 @@ FlipDevice &FluidDomain::device() {
         _solid_version_on_device = 0;
         _fluid_version_on_device = 0;
         _object_on_device = false;
+        _fluid_device_newer = false;
     }
     if (_solid_version_on_device != _solid_level_set.version()) {
         _device->uploadFloat(FLIP_F_PHI_SOLID, solid);
         _solid_version_on_device = _solid_level_set.version();
     }
-    if (_fluid_version_on_device != _fluid_level_set.version()) {
+    if (!_fluid_device_newer && _fluid_version_on_device != _fluid_level_set.version()) {
         _device->uploadFloat(FLIP_F_PHI_FLUID, *_fluid_level_set.getLevelSet());
         _fluid_version_on_device = _fluid_level_set.version();
     }
@@ -61,19 +62,29 @@ FlipDevice &FluidDomain::device() {
 }
 
 // src/FluidDomain.cpp:50-61: union of the particles' balls, merged with the solid so that the fluid surface
-// continues into the wall (IntersectSolidFluidLevelSets), over the fluid's own topology.
+// continues into the wall (IntersectSolidFluidLevelSets).  Computed on the device from the sorted particles
+// (flip_fluid_levelset_from_particles); LevelSet::unionOfBalls is the same computation on the host for callers that
+// use a LevelSet on its own.
 void FluidDomain::constructFluidLevelSetFromMarkerParticles() {
     if (particle_set.size() > 0) {
-        const CoordBBox box = _solid_level_set.getActiveCoordBBox();
-        _fluid_level_set.unionOfBalls(particle_set, _voxel_size, box, kFluidHalfWidth);
-        FloatGrid &fluid = *_fluid_level_set.getLevelSet();
-        const FloatGrid &solid = *_solid_level_set.getLevelSet();
-        fluid.setTransform(_i2w_transform);
-        float *f = fluid.raw();
-        const float *s = solid.raw();
-        for (int64_t q = 0; q < fluid.size(); ++q) f[q] = IntersectSolidFluidLevelSets::intersect(f[q], s[q]);
-        _fluid_level_set.touch();
+        FlipDevice &dev = device();
+        particle_set.push();
+        dev.check(flip_bin_particles(dev.ctx(), nullptr), "flip_bin_particles");
+        dev.check(flip_fluid_levelset_from_particles(dev.ctx(), particle_set.getMinRadius(), kFluidHalfWidth),
+                  "flip_fluid_levelset_from_particles");
+        _fluid_device_newer = true;
     }
+}
+
+LevelSet &FluidDomain::fluidLevelSet() {
+    if (_fluid_device_newer && _device) {
+        auto g = _device->downloadFloat(FLIP_F_PHI_FLUID, kFluidHalfWidth * _voxel_size);
+        g->setTransform(_i2w_transform);
+        _fluid_level_set.setLevelSet(g);
+        _fluid_version_on_device = _fluid_level_set.version();
+        _fluid_device_newer = false;
+    }
+    return _fluid_level_set;
 }
 
 void FluidDomain::syncSolidObject() {

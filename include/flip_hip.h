@@ -165,6 +165,11 @@ int flip_advect_particles(flip_ctx *ctx, float dt);
 int flip_mark_valid_from_active(flip_ctx *ctx);
 /* FluidSimulator::extrapolate_data (src/FluidSimulator.cpp:181-265). */
 int flip_extrapolate(flip_ctx *ctx, int iterations);
+/* FluidDomain::constructFluidLevelSetFromMarkerParticles (src/FluidDomain.cpp:50-61) with LevelSet::unionOfBalls
+ * (src/LevelSet.cpp:17-23): FLIP_F_PHI_FLUID = distance to the nearest particle minus radius_world, clipped to
+ * +-half_width_voxels voxels, merged with the solid level set (headers/LevelSet.h:83-96).  Exact distances; the
+ * reference's OpenVDB rasterisation is not available to compare with.  Needs flip_bin_particles first. */
+int flip_fluid_levelset_from_particles(flip_ctx *ctx, float radius_world, float half_width_voxels);
 /* FluidSimulator::constrain_velocity (src/FluidSimulator.cpp:1180-1247; rigid_body != 0: the overload for the
  * attached SolidObject, :1249-1321, with the velocity last given to flip_solid_object_set or updated by
  * flip_project_velocity).  Uses the face fractions currently stored, as the reference does. */

@@ -492,3 +492,21 @@ def test_constrain_velocity_matches_the_oracle():
         n = 16
         k, j, i = np.argwhere(w[1] == 1)[0]
         assert abs(got[1][k, j, i]) <= np.abs(uvw[1]).max()
+
+
+def test_fluid_levelset_from_particles_is_the_exact_union_of_balls():
+    """flip_fluid_levelset_from_particles against an independent nearest-neighbour search (k-d tree) on the same
+    particles: identical up to the last bits of the distance (the two sum the squares in their own order)."""
+    sc = scenes.dam_break(24, ppc=4, seed=13)
+    radius_index = 1.01 * np.sqrt(3.0) / 2.0        # src/FluidSource.cpp:67 in voxels
+    want = scenes.fluid_levelset(sc, sc.pos)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        ctx.bin_particles()
+        ctx.fluid_levelset_from_particles(radius_index * float(np.float32(sc.dx)), 3.0)
+        got = ctx.download("phi_fluid")
+        ctx.bin_particles()                          # the sort is still current: returns without re-sorting
+        assert ctx.bin_particles() == 0
+    assert np.abs(got - want).max() <= 2e-6 * float(sc.dx)
+    assert np.array_equal(got < 0, want < 0)
+    assert (got < 0).sum() > 1000 and (got == got.max()).sum() > 1000
