@@ -54,6 +54,9 @@ def parse():
                     help="N > 1: z-slab decomposition of one long domain (auto) or independent replicas")
     ap.add_argument("--ghost", type=int, default=8, help="ghost planes on either side of a slab")
     ap.add_argument("--split-phase", action="store_true", help="N = 1: drive the solver through the split-phase entry points")
+    ap.add_argument("--full-substep", action="store_true",
+                    help="N = 1: also rebuild the level set from the particles, constrain_velocity and RK3 advection (the whole "
+                         "loop body of advance_flip_pic except the fluid source); informational, not the headline configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=40, help="CG iterations per solve timed on the CPU")
     return ap.parse_args()
@@ -177,7 +180,10 @@ def main():
     if slabs:
         step = DistributedSubstep(ctx, layout, Comm(), device=local, tol=args.tol, max_iter=args.max_iter, precond=precond)
     else:
-        step = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=precond)
+        extra = {}
+        if args.full_substep:
+            extra = dict(constrain=True, advect=True, levelset_radius=1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0)
+        step = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=precond, **extra)
 
     def barrier():
         ctx.synchronize()
@@ -236,7 +242,7 @@ def main():
                       "frac": g2p_bytes / t_g2p / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_g2p * 1e6,
                       "algorithmic_bytes": g2p_bytes},
         }
-        if world == 1 and not args.no_cpu_baseline and not slabs:
+        if world == 1 and not args.no_cpu_baseline and not slabs and not args.full_substep:
             # iteration counts of the reference's own solver (Jacobi CG) on this scene, for the CPU extrapolation
             probe = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=PRECOND_JACOBI).step(args.dt)
             jacobi_iters = (probe["divergence"]["iterations"], probe["density"]["iterations"])
@@ -260,7 +266,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"dam break {args.n}^3" + (f" x{world} along z" if world > 1 and slabs else "")
-                                   + f", {args.ppc} particles/cell, density projection on, {args.precond} PCG tol {args.tol:g}",
+                                   + f", {args.ppc} particles/cell, density projection on, {args.precond} PCG tol {args.tol:g}"
+                                   + (", with level set rebuild, constrain_velocity and advection" if args.full_substep else ""),
                        "cells": tot_cells, "particles": tot_particles, "rows": tot_rows, "parallelism": parallelism},
             "pcg": {"iterations_per_step": iters / args.steps, "seconds_per_step": pcg_s / args.steps,
                     "effective_GBps": pcg_gbs, "pct_hbm_peak": 100.0 * pcg_gbs / HBM_PEAK_GBS,

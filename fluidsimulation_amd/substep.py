@@ -3,7 +3,7 @@
 Mirrors the order of FluidSimulator::advance_flip_pic (src/FluidSimulator.cpp:307-446) for the stages
 that are on the device.  Fluid sources and the level set from particles are not part of it: the level sets
 are inputs.  `constrain=True` adds the two constrain_velocity calls (:357-361, :404-408) and `advect=True` the
-RK3 particle advection (:426); both default to off, which is the configuration the benchmark and the parity tests'
+RK3 particle advection (:426), `levelset_radius` rebuilds the fluid level set from the particles (:324); all default to off, which is the configuration the benchmark and the parity tests'
 reference substep use (the particles then move only by the density-projection displacements).
 """
 from __future__ import annotations
@@ -14,7 +14,7 @@ from .binding import FlipContext, PRECOND_JACOBI, SOLVE_DENSITY, SOLVE_DIVERGENC
 class FlipSubstep:
     def __init__(self, ctx: FlipContext, flip_pic_ratio: float = 0.95, tol: float = 1e-15, max_iter: int = 0,
                  precond: int = PRECOND_JACOBI, density_projection: bool = True, constrain: bool = False,
-                 advect: bool = False, rigid_body: bool = False):
+                 advect: bool = False, rigid_body: bool = False, levelset_radius: float | None = None):
         self.ctx = ctx
         self.ratio = flip_pic_ratio      # main.cpp:167
         self.tol = tol                   # src/FluidSimulator.cpp:660
@@ -22,6 +22,7 @@ class FlipSubstep:
         self.precond = precond
         self.density_projection = density_projection   # DENSITY_CONSTRAINT_PPE, src/FluidSimulator.cpp:31
         self.constrain, self.advect, self.rigid_body = constrain, advect, rigid_body
+        self.levelset_radius = levelset_radius   # world units; None: the fluid level set is an input
         self.info = {}
 
     def _constrain(self):
@@ -33,6 +34,8 @@ class FlipSubstep:
     def step(self, dt: float) -> dict:
         c = self.ctx
         c.bin_particles(want_outside=False)
+        if self.levelset_radius is not None:
+            c.fluid_levelset_from_particles(self.levelset_radius)   # :324
         c.p2g()                                   # :337
         c.mark_valid_from_active()                # :343-345
         c.extrapolate(2)                          # :349
