@@ -123,6 +123,25 @@ def cpu_baseline(sc, args, jacobi_iters):
             "stage_seconds": {k: round(v, 4) for k, v in t.items()}}
 
 
+def stored_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this very command (FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs, so they cannot be read live here): 2 x FETCH_SIZE (the gfx950 correction
+    for streaming reads) + WRITE_SIZE, both reported in KB.  None when the files are absent."""
+    import csv
+    vals = {}
+    for key, name in (("fetch", "r01_c_bench256_mg_pmc_fetch_size.csv"), ("write", "r01_c_bench256_mg_pmc_write_size.csv")):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            return None
+        with open(path, newline="") as f:
+            for row in csv.reader(f):
+                if row and row[0].startswith(kernel_prefix):
+                    vals[key] = float(row[2])
+    if len(vals) != 2:
+        return None
+    return (2.0 * vals["fetch"] + vals["write"]) * 1024.0
+
+
 def time_stage(torch, fn, reps=3):
     """Average device time of `fn` (kernels on torch's current stream, which is the context's stream)."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -247,6 +266,9 @@ def main():
             probe = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=PRECOND_JACOBI).step(args.dt)
             jacobi_iters = (probe["divergence"]["iterations"], probe["density"]["iterations"])
 
+    traffic = None
+    if rank == 0 and world == 1 and args.n == 256 and args.ppc == 8 and args.precond == "mg" and not args.full_substep:
+        traffic = stored_traffic("void k_pcg_direction<true>")
     if rank == 0:
         parallelism = "single GPU"
         if world > 1:
@@ -274,7 +296,10 @@ def main():
                     "bytes_per_row_per_iteration": it_bytes, "rows_this_rank": rows,
                     "converged": all(s["converged"] == 1 for s in solves)},
             "roofline": {"bound": "hbm", "kernel": "k_pcg_direction", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
+                         "traffic_source": "profiles/r01_c_bench256_mg_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc "
+                                           "passes of this command; 2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)" if traffic else None,
+                         "algorithmic_bytes_per_launch": rows * DIRECTION_BYTES_PER_ROW,
                          "bytes_per_row": DIRECTION_BYTES_PER_ROW, "rows_per_launch": rows,
                          "avg_launch_us": avg_launch * 1e6 if avg_launch else None, "launches_timed": spmv_n},
             "roofline_other_kernels": kernels,
