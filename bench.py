@@ -11,8 +11,8 @@ before the timed region.  Rank 0 prints ONE JSON line.
 N = 1: one context, the fused solver loop.
 N > 1: z-slab decomposition, one process per GPU (fluidsimulation_amd/distributed.py): the container is N
 times as long along z and every rank owns one 256^3-sized slab of it plus ghost planes (weak scaling); the CG
-scalars are all-reduced and one plane per slab face is exchanged every iteration over RCCL, particles near a
-face are exchanged once per step.  `value` counts slab-substeps: N x (substeps of the long domain) per second.
+scalars are all-reduced and a few planes per slab face are exchanged every iteration over RCCL (overlapping
+additive-Schwarz preconditioner), particles near a face are exchanged once per step.  `value` counts slab-substeps: N x (substeps of the long domain) per second.
 """
 import argparse
 import json
@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--parallel", default="auto", choices=["auto", "slabs", "replicas"],
                     help="N > 1: z-slab decomposition of one long domain (auto) or independent replicas")
     ap.add_argument("--ghost", type=int, default=8, help="ghost planes on either side of a slab")
+    ap.add_argument("--overlap", type=int, default=int(os.environ.get("FLIP_BENCH_OVERLAP", "-1")),
+                    help="N > 1: planes of either neighbour's slab the local preconditioner also covers (additive Schwarz); "
+                         "0 = disjoint blocks, default 4")
     ap.add_argument("--split-phase", action="store_true", help="N = 1: drive the solver through the split-phase entry points")
     ap.add_argument("--full-substep", action="store_true",
                     help="N = 1: also rebuild the level set from the particles, constrain_velocity and RK3 advection (the whole "
@@ -197,7 +200,9 @@ def main():
     ctx.reserve_particles(sc.pos.shape[0] * 5 // 4 + 4096)
     ctx.upload_scene(sc)
     if slabs:
-        step = DistributedSubstep(ctx, layout, Comm(), device=local, tol=args.tol, max_iter=args.max_iter, precond=precond)
+        overlap = min(4 if args.overlap < 0 else args.overlap, max(args.ghost - 1, 0)) if world > 1 else 0
+        step = DistributedSubstep(ctx, layout, Comm(), device=local, tol=args.tol, max_iter=args.max_iter, precond=precond,
+                                  overlap=overlap)
     else:
         extra = {}
         if args.full_substep:
@@ -272,8 +277,8 @@ def main():
     if rank == 0:
         parallelism = "single GPU"
         if world > 1:
-            parallelism = (f"{world} z-slabs of one {world}x long domain, ghost {args.ghost}, RCCL all-reduce + plane exchange per "
-                           f"CG iteration" if slabs else f"{world} independent replicas")
+            parallelism = (f"{world} z-slabs of one {world}x long domain, ghost {args.ghost}, preconditioner overlap {overlap}, RCCL "
+                           f"all-reduces + plane exchanges per CG iteration" if slabs else f"{world} independent replicas")
         out = {
             "metric": "FLIP substeps/s (hot path; 256^3-sized slab per MI355X) + PCG GB/s",
             "value": world * args.steps / elapsed,

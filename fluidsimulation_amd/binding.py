@@ -64,7 +64,8 @@ EXPORTS = [
     "flip_density", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
     "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_project_velocity",
     "flip_project_displacement", "flip_set_slab", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
-    "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish", "flip_particles_reserve", "flip_particles_pack",
+    "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish", "flip_set_slab_overlap",
+    "flip_pcg_dist_precondition", "flip_pcg_dist_combine", "flip_particles_reserve", "flip_particles_pack",
     "flip_particles_exchange_apply",
 ]
 
@@ -128,6 +129,9 @@ def load_library(path: str = LIB_PATH):
         "flip_pcg_dist_update": (C.c_int, [vp]),
         "flip_pcg_dist_status": (C.c_int, [vp, P(i32), P(i32)]),
         "flip_pcg_dist_finish": (C.c_int, [vp, P(PcgInfo)]),
+        "flip_set_slab_overlap": (C.c_int, [vp, i32]),
+        "flip_pcg_dist_precondition": (C.c_int, [vp]),
+        "flip_pcg_dist_combine": (C.c_int, [vp]),
         "flip_particles_reserve": (C.c_int, [vp, i64]),
         "flip_particles_pack": (C.c_int, [vp, i32, i32, vp, i64, P(i64)]),
         "flip_particles_exchange_apply": (C.c_int, [vp, vp, i64, vp, i64]),
@@ -349,8 +353,18 @@ class FlipContext:
     def set_slab(self, k0: int, k1: int):
         self._check(self.lib.flip_set_slab(self.h, k0, k1))
 
+    def set_slab_overlap(self, planes: int):
+        self._check(self.lib.flip_set_slab_overlap(self.h, planes))
+
+    def dist_precondition(self):
+        self._check(self.lib.flip_pcg_dist_precondition(self.h))
+
+    def dist_combine(self):
+        self._check(self.lib.flip_pcg_dist_combine(self.h))
+
     def dist_buffer(self, which: int):
-        """(device pointer, element count) of buffer 0 (sums), 1 (z) or 2 (x); elements are doubles."""
+        """(device pointer, element count) of buffer 0 (sums), 1 (z), 2 (x), 3 (r), 4 / 5 (corrections received from
+        the lower / upper neighbour, overlapping variant only); elements are doubles."""
         ptr, n = C.c_void_p(), C.c_int64(0)
         self._check(self.lib.flip_pcg_dist_buffer(self.h, which, C.byref(ptr), C.byref(n)))
         return ptr.value, n.value

@@ -76,7 +76,8 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
     dfree(c->cg_scan); dfree(c->cg_rows);
     dfree(c->chunk_flag); dfree(c->chunk_list); dfree(c->d_counts); dfree(c->partial); dfree(c->scal);
     if (c->mg_cz) (void)hipFree(c->mg_cz - c->pad);
-    dfree(c->dist_sums);
+    dfree(c->dist_sums); dfree(c->mg_rows); dfree(c->dist_recv[0]); dfree(c->dist_recv[1]);
+    if (c->dist_rw) (void)hipFree(c->dist_rw - c->pad);
     dfree(c->d_vmax);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;

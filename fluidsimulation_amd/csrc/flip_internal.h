@@ -152,6 +152,14 @@ struct flip_ctx {
     double *dist_sums = nullptr;    // [8] local sums handed to the caller's all-reduce
     bool dist_active = false, dist_mg = false;
     int32_t dist_max_iter = 0;
+    int dist_prof = 0;              // direction launches bracketed by events in this solve (profiling)
+    // overlapping variant (flip_set_slab_overlap): the local preconditioner also covers `slab_overlap` planes of either
+    // neighbour's slab; the residual there comes from the neighbour and the correction computed there goes back to it
+    int32_t slab_overlap = 0;
+    int32_t *mg_rows = nullptr;     // [B] rows of planes [slab_k0 - overlap, slab_k1 + overlap); count in d_counts[7]
+    double *dist_recv[2] = {};      // [(overlap + 1) planes] corrections received from the lower / upper neighbour
+    bool slab_weighted = false;     // partition-of-unity weights across the overlap (see flip_set_slab_overlap)
+    double *dist_rw = nullptr;      // weighted copy of the residual, the V-cycle's right-hand side when slab_weighted
 };
 
 int flip_mg_setup(flip_ctx *ctx);   // coarse operators of the assembled system

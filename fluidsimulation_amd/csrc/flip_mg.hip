@@ -397,6 +397,8 @@ static int mg_ensure_levels(flip_ctx *ctx) {
 
 static MgDev<float> mg_level0(flip_ctx *ctx) {
     MgDev<float> L;
+    // with an overlapping slab preconditioner: the rows of the widened region, and the weighted residual if weights are on
+    const bool wide = ctx->slab_on && ctx->slab_overlap > 0;
     L.B = ctx->B; L.sy = ctx->g.nx; L.sz = (long long)ctx->g.nx * ctx->g.ny;
     L.nx = ctx->g.nx; L.ny = ctx->g.ny; L.nz = ctx->g.nz;
     // in slab mode the preconditioner is local to the rank: no coupling across the slab faces
@@ -404,8 +406,8 @@ static MgDev<float> mg_level0(flip_ctx *ctx) {
     L.scale = ctx->sys_s2;
     { const MgCheb k = mg_cheb(); L.c1 = k.c1; L.a2 = k.a2; L.c2 = k.c2; }
     L.diag = ctx->mg_diag_f; L.inv = ctx->mg_inv_f;
-    L.x = ctx->z; L.b = ctx->r; L.t = ctx->ap;   // z = M^-1 r; Ap is free between the update and direction kernels
-    L.rows = ctx->cg_rows; L.n_rows = ctx->d_counts + 6;
+    L.x = ctx->z; L.b = (wide && ctx->slab_weighted) ? ctx->dist_rw : ctx->r; L.t = ctx->ap;   // z = M^-1 r; Ap is free between the update and direction kernels
+    L.rows = wide ? ctx->mg_rows : ctx->cg_rows; L.n_rows = ctx->d_counts + (wide ? 7 : 6);
     return L;
 }
 static MgDev<double> mg_level(const flip_mg_level &S) {
@@ -501,7 +503,10 @@ int flip_mg_vcycle(flip_ctx *ctx) {
         k_mg_smooth<double, false><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.t, F.x, nullptr);
     }
     k_mg_post<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x, L0.t);
-    k_mg_smooth<float, true><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.t, L0.x, ctx->partial + 1 * FLIP_MAX_PCG_BLOCKS);
+    if (ctx->slab_on && ctx->slab_overlap > 0) // r.z waits for the neighbours' share of z (flip_pcg_dist_combine)
+        k_mg_smooth<float, false><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.t, L0.x, nullptr);
+    else
+        k_mg_smooth<float, true><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.t, L0.x, ctx->partial + 1 * FLIP_MAX_PCG_BLOCKS);
     FLIP_LAUNCH_CHECK();
     return 0;
 }

@@ -16,6 +16,8 @@
 // hold the same scalar and the result is reproducible run to run.
 #include "flip_internal.h"
 
+#include <cstdlib>
+
 #include <cfloat>
 
 // ---------------------------------------------------------------------------------------------
@@ -177,16 +179,27 @@ __global__ void k_compact_cg_rows(long long B, long long own_lo, long long own_h
     if (c >= B) return;
     if (c >= own_lo && c < own_hi && (flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW) rows[scan[c]] = (int32_t)c;
 }
-// Slab mode: ghost cells are not rows of the local CG system (diagonal and Jacobi inverse zero), and the local
-// preconditioner sees no coupling across the two slab faces (stored with the cell on the high side of a face).
-__global__ void k_slab_mask(long long B, long long sz, long long own_lo, long long own_hi, const float *__restrict__ cgz,
+// Slab mode: [reg_lo, reg_hi) are the cells the local preconditioner covers (the owned planes, widened by the
+// overlap).  Cells outside it are not rows of anything local (diagonal and Jacobi inverse zero), and the
+// preconditioner sees no coupling across the two faces of the region (stored with the cell on the high side).
+__global__ void k_slab_mask(long long B, long long sz, long long reg_lo, long long reg_hi, const float *__restrict__ cgz,
                             float *__restrict__ mg_cz, double *__restrict__ cg_diag, double *__restrict__ cg_inv) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= B) return;
-    const bool owned = c >= own_lo && c < own_hi;
-    if (!owned) { cg_diag[c] = 0.0; cg_inv[c] = 0.0; }
-    const bool on_face = (c >= own_lo && c < own_lo + sz) || (c >= own_hi && c < own_hi + sz);
-    mg_cz[c] = (owned && !on_face) ? cgz[c] : 0.f;
+    const bool inside = c >= reg_lo && c < reg_hi;
+    if (!inside) { cg_diag[c] = 0.0; cg_inv[c] = 0.0; }
+    const bool on_face = (c >= reg_lo && c < reg_lo + sz) || (c >= reg_hi && c < reg_hi + sz);
+    mg_cz[c] = (inside && !on_face) ? cgz[c] : 0.f;
+}
+__global__ void k_mark_region_rows(long long B, long long lo, long long hi, const double *__restrict__ cg_inv, int32_t *__restrict__ mark) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > B) return;
+    mark[c] = (c >= lo && c < hi && cg_inv[c] != 0.0) ? 1 : 0;
+}
+__global__ void k_compact_region_rows(long long B, const int32_t *__restrict__ scan, int32_t *__restrict__ rows) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    if (scan[c + 1] > scan[c]) rows[scan[c]] = (int32_t)c;
 }
 
 extern "C" int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1) {
@@ -207,7 +220,47 @@ extern "C" int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1) {
         FLIP_CHECK(hipMalloc((void **)&ctx->dist_sums, 8 * sizeof(double)));
         FLIP_CHECK(hipMemset(ctx->dist_sums, 0, 8 * sizeof(double)));
     }
+    ctx->slab_overlap = 0;
     ctx->sys_kind = -1; // a system assembled under another ownership is stale
+    return 0;
+}
+
+extern "C" int flip_set_slab_overlap(flip_ctx *ctx, int32_t planes) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(ctx->dist_sums, "flip_set_slab_overlap: call flip_set_slab first");
+    FLIP_REQUIRE(planes >= 0, "flip_set_slab_overlap: the overlap cannot be negative");
+    FLIP_REQUIRE(!ctx->dist_active, "flip_set_slab_overlap: a solve is in progress");
+    // a face with a neighbour behind it has ghost planes; the overlap must fit into them
+    FLIP_REQUIRE(ctx->slab_k0 == 0 || planes <= ctx->slab_k0, "flip_set_slab_overlap: more planes than the lower ghost zone holds");
+    FLIP_REQUIRE(ctx->slab_k1 == ctx->g.nz || planes <= ctx->g.nz - ctx->slab_k1,
+                 "flip_set_slab_overlap: more planes than the upper ghost zone holds");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    const size_t plane = (size_t)ctx->g.nx * ctx->g.ny;
+    if (planes != ctx->slab_overlap) {
+        for (int s = 0; s < 2; ++s)
+            if (ctx->dist_recv[s]) { FLIP_CHECK(hipFree(ctx->dist_recv[s])); ctx->dist_recv[s] = nullptr; }
+    }
+    if (planes > 0 && ctx->slab_on) {
+        if (!ctx->mg_rows) FLIP_CHECK(hipMalloc((void **)&ctx->mg_rows, (size_t)ctx->B * 4));
+        for (int s = 0; s < 2; ++s)
+            if (!ctx->dist_recv[s]) {
+                FLIP_CHECK(hipMalloc((void **)&ctx->dist_recv[s], (size_t)(planes + 1) * plane * 8));
+                FLIP_CHECK(hipMemset(ctx->dist_recv[s], 0, (size_t)(planes + 1) * plane * 8));
+            }
+    }
+    ctx->slab_overlap = ctx->slab_on ? planes : 0;
+    ctx->slab_weighted = false;
+    if (ctx->slab_overlap > 0) {
+        const char *e = getenv("FLIP_SLAB_WEIGHTED");
+        ctx->slab_weighted = !(e && atoi(e) == 0);
+    }
+    if (ctx->slab_weighted && !ctx->dist_rw) {
+        double *base = nullptr;
+        FLIP_CHECK(hipMalloc((void **)&base, (size_t)(ctx->B + 2 * ctx->pad) * sizeof(double)));
+        FLIP_CHECK(hipMemset(base, 0, (size_t)(ctx->B + 2 * ctx->pad) * sizeof(double)));
+        ctx->dist_rw = base + ctx->pad;
+    }
+    ctx->sys_kind = -1;
     return 0;
 }
 
@@ -278,9 +331,21 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     const long long plane = (long long)ctx->g.nx * ctx->g.ny;
     const long long own_lo = ctx->slab_on ? ctx->slab_k0 * plane : 0, own_hi = ctx->slab_on ? ctx->slab_k1 * plane : ctx->B;
     if (ctx->slab_on) {
-        k_slab_mask<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, plane, own_lo, own_hi, ctx->cg_c[2], ctx->mg_cz,
+        const int ov = ctx->slab_overlap;
+        const long long reg_lo = (ctx->slab_k0 > ov ? ctx->slab_k0 - ov : 0) * plane;
+        const long long reg_hi = (ctx->slab_k1 + ov < ctx->g.nz ? ctx->slab_k1 + ov : ctx->g.nz) * plane;
+        k_slab_mask<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, plane, reg_lo, reg_hi, ctx->cg_c[2], ctx->mg_cz,
                                                                     ctx->cg_diag, ctx->cg_inv);
         FLIP_LAUNCH_CHECK();
+        if (ov > 0) {
+            // rows of the preconditioner's region (ascending cell ids), the CG rows among them
+            k_mark_region_rows<<<flip_grid_blocks(ctx->B + 1), FLIP_BLOCK, 0, st>>>(ctx->B, reg_lo, reg_hi, ctx->cg_inv, ctx->cg_scan);
+            FLIP_LAUNCH_CHECK();
+            if (int rc = flip_exclusive_scan(ctx, ctx->cg_scan, ctx->B + 1)) return rc;
+            k_compact_region_rows<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, ctx->cg_scan, ctx->mg_rows);
+            FLIP_LAUNCH_CHECK();
+            FLIP_CHECK(hipMemcpyAsync(ctx->d_counts + 7, ctx->cg_scan + ctx->B, 4, hipMemcpyDeviceToDevice, st));
+        }
     }
     k_mark_cg_rows<<<flip_grid_blocks(ctx->B + 1), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan);
     FLIP_LAUNCH_CHECK();
@@ -764,6 +829,64 @@ __global__ void k_dist_ghost_direction(flip_pcg_scalars *S, long long plane, lon
     if (hi_ghost >= 0) { const long long c = hi_ghost + q; pnew[c] = z[c] + beta * pold[c]; z[c] = 0.0; }
 }
 
+// Weights of the overlapping variant: across the 2m planes around a slab face this rank's weight rises linearly
+// from 0 (far side) to 1 (own side) and the neighbour's falls likewise, so the two add up to one.  The
+// preconditioner is sum_i R_i^T W_i M_i W_i R_i with W_i the square roots: symmetric, and a cell of the
+// overlap is no longer corrected twice.
+struct SlabWeight { int k0, k1, m, has_lo, has_hi; long long plane; };
+static SlabWeight slab_weight(const flip_ctx *ctx) {
+    SlabWeight W;
+    W.k0 = ctx->slab_k0; W.k1 = ctx->slab_k1; W.m = ctx->slab_overlap;
+    W.has_lo = ctx->slab_k0 > 0; W.has_hi = ctx->slab_k1 < ctx->g.nz;
+    W.plane = (long long)ctx->g.nx * ctx->g.ny;
+    return W;
+}
+__device__ __forceinline__ double d_slab_weight(const SlabWeight &W, int k) {
+    double w = 1.0;
+    if (W.has_lo && k < W.k0 + W.m) { const double t = ((double)(k - (W.k0 - W.m)) + 0.5) / (2.0 * W.m); w = t > 0.0 ? sqrt(t) : 0.0; }
+    if (W.has_hi && k >= W.k1 - W.m) { const double t = ((double)(W.k1 + W.m - 1 - k) + 0.5) / (2.0 * W.m); w *= t > 0.0 ? sqrt(t) : 0.0; }
+    return w;
+}
+__global__ void __launch_bounds__(FLIP_BLOCK) k_dist_weight_r(const flip_pcg_scalars *S, SlabWeight W, const int32_t *__restrict__ rows,
+                                                             const int32_t *__restrict__ n_rows, const double *__restrict__ r,
+                                                             double *__restrict__ rw) {
+    if (S->done) return;
+    const long long n = *n_rows;
+    for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
+        const long long c = rows[q];
+        rw[c] = d_slab_weight(W, (int)(c / W.plane)) * r[c];
+    }
+}
+__global__ void k_dist_weight_z(const flip_pcg_scalars *S, SlabWeight W, long long base, long long n, double *__restrict__ z) {
+    if (S->done) return;
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const long long c = base + q;
+    z[c] *= d_slab_weight(W, (int)(c / W.plane));
+}
+
+// Overlapping variant: the correction a neighbour computed on its copy of these cells is added to the local one
+// (cells that are rows only), and r.z is taken over the owned rows once z is final.
+__global__ void k_dist_add(const flip_pcg_scalars *S, long long n, const double *__restrict__ inv, const double *__restrict__ recv,
+                           double *__restrict__ z) {
+    if (S->done) return;
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n && inv[q] != 0.0) z[q] += recv[q];
+}
+__global__ void __launch_bounds__(FLIP_BLOCK) k_dist_rz(PcgArgs A) {
+    __shared__ double scratch[4];
+    if (A.scal->done) return;
+    long long lo, hi;
+    d_row_range(A, lo, hi);
+    double rz = 0.0;
+    for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
+        const long long c = A.rows[q];
+        rz += A.r[c] * A.z[c];
+    }
+    rz = d_block_sum(rz, scratch);
+    if (threadIdx.x == 0) A.partial[1 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rz;
+}
+
 extern "C" int flip_pcg_dist_buffer(flip_ctx *ctx, int which, void **ptr, int64_t *count) {
     FLIP_REQUIRE(ctx && ptr && count, "flip_pcg_dist_buffer: null argument");
     FLIP_REQUIRE(ctx->dist_sums, "flip_pcg_dist_buffer: call flip_set_slab first");
@@ -771,6 +894,13 @@ extern "C" int flip_pcg_dist_buffer(flip_ctx *ctx, int which, void **ptr, int64_
     case 0: *ptr = ctx->dist_sums; *count = 8; break;
     case 1: *ptr = ctx->z; *count = ctx->B; break;
     case 2: *ptr = ctx->x; *count = ctx->B; break;
+    case 3: *ptr = ctx->r; *count = ctx->B; break;
+    case 4:
+    case 5:
+        FLIP_REQUIRE(ctx->slab_overlap > 0, "flip_pcg_dist_buffer: no overlap set (flip_set_slab_overlap)");
+        *ptr = ctx->dist_recv[which - 4];
+        *count = (int64_t)(ctx->slab_overlap + 1) * ctx->g.nx * ctx->g.ny;
+        break;
     default: FLIP_REQUIRE(false, "flip_pcg_dist_buffer: unknown buffer");
     }
     return 0;
@@ -805,6 +935,7 @@ extern "C" int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, 
     ctx->dist_mg = use_mg;
     ctx->dist_max_iter = max_iter;
     ctx->dist_active = true;
+    ctx->dist_prof = 0;
     PcgArgs A;
     fill_pcg_args(ctx, A);
     const int nblk = ctx->pcg_blocks;
@@ -816,6 +947,7 @@ extern "C" int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, 
     FLIP_CHECK(hipEventRecord(ctx->events[0], st));
     k_pcg_init<<<nblk, FLIP_BLOCK, 0, st>>>(A);
     FLIP_LAUNCH_CHECK();
+    if (ctx->slab_overlap > 0) return 0; // the caller continues with the residual exchange, precondition() and combine()
     if (use_mg)
         if (int rc = flip_mg_vcycle(ctx)) return rc;
     k_dist_gather<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 0, 2, ctx->dist_sums);
@@ -831,7 +963,10 @@ extern "C" int flip_pcg_dist_direction(flip_ctx *ctx) {
     fill_pcg_args(ctx, A);
     const int nblk = ctx->pcg_blocks;
     k_dist_scatter<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 0, 2, ctx->dist_sums);
+    const bool prof = ctx->profiling && ctx->dist_prof < 64;
+    if (prof) FLIP_CHECK(hipEventRecord(ctx->events[2 + 2 * ctx->dist_prof], st));
     k_pcg_direction<true><<<nblk, FLIP_BLOCK, 0, st>>>(A);
+    if (prof) { FLIP_CHECK(hipEventRecord(ctx->events[3 + 2 * ctx->dist_prof], st)); ++ctx->dist_prof; }
     const long long plane = (long long)ctx->g.nx * ctx->g.ny;
     const long long lo_ghost = ctx->slab_on && ctx->slab_k0 > 0 ? (ctx->slab_k0 - 1) * plane : -1;
     const long long hi_ghost = ctx->slab_on && ctx->slab_k1 < ctx->g.nz ? ctx->slab_k1 * plane : -1;
@@ -852,8 +987,60 @@ extern "C" int flip_pcg_dist_update(flip_ctx *ctx) {
     const int nblk = ctx->pcg_blocks;
     k_dist_scatter<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 2, 1, ctx->dist_sums);
     k_pcg_update<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+    FLIP_LAUNCH_CHECK();
+    if (ctx->slab_overlap > 0) return 0;
     if (ctx->dist_mg)
         if (int rc = flip_mg_vcycle(ctx)) return rc;
+    k_dist_gather<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 0, 2, ctx->dist_sums);
+    FLIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Overlapping variant, after the neighbours' residuals have arrived in the overlap planes of buffer 3: the local
+// preconditioner over the owned planes and the overlap (z = Jacobi of the owned rows already when it is Jacobi).
+extern "C" int flip_pcg_dist_precondition(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx && ctx->dist_active, "flip_pcg_dist_precondition: no solve in progress");
+    FLIP_REQUIRE(ctx->slab_overlap > 0, "flip_pcg_dist_precondition: no overlap set (flip_set_slab_overlap)");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->dist_mg) return 0;
+    hipStream_t st = ctx->stream;
+    const SlabWeight W = slab_weight(ctx);
+    if (ctx->slab_weighted) {
+        k_dist_weight_r<<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(ctx->scal, W, ctx->mg_rows, ctx->d_counts + 7, ctx->r, ctx->dist_rw);
+        FLIP_LAUNCH_CHECK();
+    }
+    if (int rc = flip_mg_vcycle(ctx)) return rc;
+    if (ctx->slab_weighted) {
+        const long long n = 2LL * W.m * W.plane;
+        if (W.has_lo) k_dist_weight_z<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(ctx->scal, W, (long long)(W.k0 - W.m) * W.plane, n, ctx->z);
+        if (W.has_hi) k_dist_weight_z<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(ctx->scal, W, (long long)(W.k1 - W.m) * W.plane, n, ctx->z);
+        FLIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// Overlapping variant, after the neighbours' corrections have arrived in buffers 4 (from the lower neighbour, for
+// planes [slab_k0 - 1, slab_k0 + overlap)) and 5 (from the upper one, for planes [slab_k1 - overlap, slab_k1 + 1)):
+// adds them, which also completes z on the first ghost plane of either side, and leaves rr and r.z in buffer 0.
+extern "C" int flip_pcg_dist_combine(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx && ctx->dist_active, "flip_pcg_dist_combine: no solve in progress");
+    FLIP_REQUIRE(ctx->slab_overlap > 0, "flip_pcg_dist_combine: no overlap set (flip_set_slab_overlap)");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    PcgArgs A;
+    fill_pcg_args(ctx, A);
+    const int nblk = ctx->pcg_blocks;
+    const long long plane = (long long)ctx->g.nx * ctx->g.ny;
+    const long long n = (long long)(ctx->slab_overlap + 1) * plane;
+    if (ctx->slab_k0 > 0) {
+        const long long base = (long long)(ctx->slab_k0 - 1) * plane;
+        k_dist_add<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(ctx->scal, n, ctx->cg_inv + base, ctx->dist_recv[0], ctx->z + base);
+    }
+    if (ctx->slab_k1 < ctx->g.nz) {
+        const long long base = (long long)(ctx->slab_k1 - ctx->slab_overlap) * plane;
+        k_dist_add<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(ctx->scal, n, ctx->cg_inv + base, ctx->dist_recv[1], ctx->z + base);
+    }
+    k_dist_rz<<<nblk, FLIP_BLOCK, 0, st>>>(A);
     k_dist_gather<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 0, 2, ctx->dist_sums);
     FLIP_LAUNCH_CHECK();
     return 0;
@@ -900,6 +1087,16 @@ extern "C" int flip_pcg_dist_finish(flip_ctx *ctx, flip_pcg_info *info) {
         float ms = 0.f;
         FLIP_CHECK(hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]));
         info->seconds = (double)ms * 1e-3;
+        double sp = 0.0;
+        int used = 0;
+        for (int q = 0; q < ctx->dist_prof && q < h.it_a; ++q) {
+            float t = 0.f;
+            FLIP_CHECK(hipEventElapsedTime(&t, ctx->events[2 + 2 * q], ctx->events[3 + 2 * q]));
+            sp += (double)t * 1e-3;
+            ++used;
+        }
+        info->spmv_seconds = sp;
+        info->spmv_launches = used;
     }
     return 0;
 }

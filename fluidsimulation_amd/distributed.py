@@ -144,6 +144,8 @@ class SlabExchange:
         self.g_of_lower = (layout.extended(rank - 1)[1] - layout.owned(rank - 1)[1]) if rank > 0 else 0
         self.g_of_upper = (layout.owned(rank + 1)[0] - layout.extended(rank + 1)[0]) if rank < layout.world - 1 else 0
 
+    overlap = 0   # planes of either neighbour's slab the local preconditioner also covers (0: disjoint blocks)
+
     def exchange_z(self, comm: Comm):
         k0, k1 = self.k0, self.k1
         comm.exchange(self.z[k0], self.z[k0 - 1] if self.g_lo else None, self.z[k1 - 1], self.z[k1] if self.g_hi else None)
@@ -154,15 +156,38 @@ class SlabExchange:
         comm.exchange(self.x[k0:k0 + self.g_of_lower], self.x[k0 - self.g_lo:k0] if self.g_lo else None,
                       self.x[k1 - self.g_of_upper:k1], self.x[k1:k1 + self.g_hi] if self.g_hi else None)
 
+    def exchange_r(self, comm: Comm):
+        """Overlapping variant: the residual on the overlap planes, from the neighbour that owns them."""
+        k0, k1, m = self.k0, self.k1, self.overlap
+        comm.exchange(self.r[k0:k0 + m], self.r[k0 - m:k0] if self.g_lo else None,
+                      self.r[k1 - m:k1], self.r[k1:k1 + m] if self.g_hi else None)
+
+    def exchange_corrections(self, comm: Comm):
+        """Overlapping variant: what this rank's preconditioner computed on the neighbours' planes goes to them,
+        together with its value on the owned plane next to the face (the neighbours' first ghost plane)."""
+        k0, k1, m = self.k0, self.k1, self.overlap
+        comm.exchange(self.z[k0 - m:k0 + 1] if self.g_lo else None, self.recv_lo,
+                      self.z[k1 - 1:k1 + m] if self.g_hi else None, self.recv_hi)
+
 
 class ContextSlabSolver(SlabExchange):
     """The split-phase solver of one FlipContext (flip_pcg_dist_*) with its buffers aliased as torch tensors."""
 
-    def __init__(self, ctx, layout: SlabLayout, rank: int, device: int):
+    def __init__(self, ctx, layout: SlabLayout, rank: int, device: int, overlap: int = 0):
         self._init_slab(layout, rank)
         self.ctx = ctx
         ctx.set_slab(self.k0, self.k1)
         nx, ny, nz = ctx.dims
+        self.overlap = int(overlap) if layout.world > 1 else 0
+        assert self.overlap <= layout.ghost, "the overlap lives in the ghost planes"
+        if self.overlap:
+            ctx.set_slab_overlap(self.overlap)
+            p, n = ctx.dist_buffer(3)
+            self.r = device_tensor(p, n, device).view(nz, nx * ny)
+            p, n = ctx.dist_buffer(4)
+            self.recv_lo = device_tensor(p, n, device).view(self.overlap + 1, nx * ny)
+            p, n = ctx.dist_buffer(5)
+            self.recv_hi = device_tensor(p, n, device).view(self.overlap + 1, nx * ny)
         p, n = ctx.dist_buffer(0)
         self.sums = device_tensor(p, n, device)
         p, n = ctx.dist_buffer(1)
@@ -179,6 +204,12 @@ class ContextSlabSolver(SlabExchange):
     def update(self):
         self.ctx.dist_update()
 
+    def precondition(self):
+        self.ctx.dist_precondition()
+
+    def combine(self):
+        self.ctx.dist_combine()
+
     def status(self):
         return self.ctx.dist_status()
 
@@ -190,17 +221,28 @@ def slab_pcg_solve(solver, comm: Comm, tol: float, max_iter: int, precond: int, 
     """Conjugate gradients over all ranks' slabs.  `solver` is a ContextSlabSolver or anything with the same
     methods (the CPU tests drive a numpy stand-in through this very loop).  Every rank executes the same number
     of iterations: the stop flag is a function of all-reduced values only."""
+    overlapping = getattr(solver, "overlap", 0) > 0
+
+    def precondition_and_sums():
+        # z = M^-1 r, then the global r.r and r.z
+        if overlapping:
+            solver.exchange_r(comm)
+            solver.precondition()
+            solver.exchange_corrections(comm)
+            solver.combine()
+        comm.all_reduce_sum(solver.sums)
+        if not overlapping:
+            solver.exchange_z(comm)
+
     solver.begin(tol, max_iter, precond)
-    comm.all_reduce_sum(solver.sums)
-    solver.exchange_z(comm)
+    precondition_and_sums()
     done = 0
     while not done:
         for _ in range(check_every):
             solver.direction()
             comm.all_reduce_sum(solver.sums)
             solver.update()
-            comm.all_reduce_sum(solver.sums)
-            solver.exchange_z(comm)
+            precondition_and_sums()
         done, _ = solver.status()
     solver.exchange_x(comm)
     return solver.finish()
@@ -270,9 +312,9 @@ class DistributedSubstep:
 
     def __init__(self, ctx, layout: SlabLayout, comm: Comm, device: int = 0, flip_pic_ratio: float = 0.95,
                  tol: float = 1e-15, max_iter: int = 20000, precond: int = PRECOND_MULTIGRID,
-                 density_projection: bool = True):
+                 density_projection: bool = True, overlap: int = 0):
         self.ctx, self.layout, self.comm = ctx, layout, comm
-        self.solver = ContextSlabSolver(ctx, layout, comm.rank, device)
+        self.solver = ContextSlabSolver(ctx, layout, comm.rank, device, overlap=overlap)
         self.ratio, self.tol, self.max_iter, self.precond = flip_pic_ratio, tol, max_iter, precond
         self.density_projection = density_projection
         # a message holds at most the sender's authoritative particles; slabs hold similar numbers of them

@@ -257,6 +257,25 @@ int flip_pcg_dist_direction(flip_ctx *ctx);
 int flip_pcg_dist_update(flip_ctx *ctx);
 int flip_pcg_dist_status(flip_ctx *ctx, int32_t *done, int32_t *iterations);
 int flip_pcg_dist_finish(flip_ctx *ctx, flip_pcg_info *info);
+/* Overlapping variant of the slab preconditioner (additive Schwarz; no counterpart in the reference).  With
+ * flip_set_slab_overlap(ctx, m), 1 <= m <= ghost planes, the local preconditioner covers planes [k0-m, k1+m): the
+ * residual on the overlap planes comes from the neighbour that owns them and the correction computed there is added to
+ * that neighbour's.  It stays symmetric positive definite and needs far fewer CG iterations than disjoint blocks when
+ * the slabs are many cells thick.  m = 0 restores the disjoint blocks.  Call it after flip_set_slab, with the same m on
+ * every rank.  The phases change as follows: begin() and update() stop before the preconditioner; the caller then
+ *   1. sends planes [k0, k0+m) and [k1-m, k1) of buffer 3 (the residual) to the lower / upper neighbour and receives
+ *      theirs into [k0-m, k0) and [k1, k1+m);
+ *   2. calls precondition();
+ *   3. sends planes [k0-m, k0+1) and [k1-1, k1+m) of buffer 1 to the lower / upper neighbour and receives theirs into
+ *      buffer 4 (from the lower neighbour) and buffer 5 (from the upper), (m+1)*nx*ny doubles each;
+ *   4. calls combine() and all-reduces buffer 0.
+ * The single-plane exchange of buffer 1 is not needed in this variant.  m must be smaller than the ghost thickness:
+ * the end of the box acts as a wall in the local matrix.  Unless the environment variable FLIP_SLAB_WEIGHTED is 0 the
+ * contributions are blended by weights that rise linearly across the 2m planes around a face (their square roots
+ * before and after the local preconditioner), so that the overlap is not corrected twice. */
+int flip_set_slab_overlap(flip_ctx *ctx, int32_t planes);
+int flip_pcg_dist_precondition(flip_ctx *ctx);
+int flip_pcg_dist_combine(flip_ctx *ctx);
 
 /* Particle exchange of the slab decomposition.  A context is authoritative for the particles its last
  * flip_bin_particles sorted into cells of its owned planes.  flip_particles_pack copies those of them whose

@@ -48,10 +48,12 @@ def _scene():
 
 
 class NumpySlabSolver:
-    """What the split-phase kernels compute, in numpy, for the communication-loop test: Jacobi-preconditioned CG
-    on the rows of the owned planes; ghost planes hold the neighbour's values."""
+    """What the split-phase kernels compute, in numpy, for the communication-loop test: preconditioned CG on the
+    rows of the owned planes; ghost planes hold the neighbour's values.  overlap = 0: point Jacobi.  overlap = m:
+    additive Schwarz, every rank applying the symmetric polynomial (2 I - D^-1 A) D^-1 of its own matrix restricted
+    to planes [k0 - m, k1 + m)."""
 
-    def __init__(self, layout, rank, label, off, diag, rhs):
+    def __init__(self, layout, rank, label, off, diag, rhs, overlap=0):
         import torch
         from fluidsimulation_amd.distributed import SlabExchange
         self._ex = SlabExchange()
@@ -64,9 +66,20 @@ class NumpySlabSolver:
         self.off, self.diag, self.rhs = off, diag, rhs
         self.xa = np.zeros(label.shape)
         self.za = np.zeros(label.shape)
+        self.ra = np.zeros(label.shape)
         self._ex.x = torch.from_numpy(self.xa).view(nz, ny * nx)
         self._ex.z = torch.from_numpy(self.za).view(nz, ny * nx)
+        self._ex.r = torch.from_numpy(self.ra).view(nz, ny * nx)
         self.sums = torch.zeros(8, dtype=torch.float64)
+        self.overlap = self._ex.overlap = overlap if layout.world > 1 else 0
+        if self.overlap:
+            m = self.overlap
+            self.region = np.zeros(label.shape, bool)
+            lo, hi = max(self.k0 - m, 0), min(self.k1 + m, nz)
+            self.region[lo:hi] = label[lo:hi] > 0
+            self.recv_lo, self.recv_hi = np.zeros((m + 1, ny, nx)), np.zeros((m + 1, ny, nx))
+            self._ex.recv_lo = torch.from_numpy(self.recv_lo).view(m + 1, ny * nx)
+            self._ex.recv_hi = torch.from_numpy(self.recv_hi).view(m + 1, ny * nx)
 
     def exchange_z(self, comm):
         self._ex.exchange_z(comm)
@@ -74,24 +87,52 @@ class NumpySlabSolver:
     def exchange_x(self, comm):
         self._ex.exchange_x(comm)
 
-    def _apply(self, p):
+    def exchange_r(self, comm):
+        self._ex.exchange_r(comm)
+
+    def exchange_corrections(self, comm):
+        self._ex.exchange_corrections(comm)
+
+    def _apply(self, p, rows=None):
+        rows = self.own if rows is None else rows
         pp = np.pad(p, 1)
         nb = [pp[1:-1, 1:-1, :-2], pp[1:-1, 1:-1, 2:], pp[1:-1, :-2, 1:-1], pp[1:-1, 2:, 1:-1], pp[:-2, 1:-1, 1:-1], pp[2:, 1:-1, 1:-1]]
         y = self.diag * p
         for f in range(6):
             y = y + self.off[f] * nb[f]
-        return np.where(self.own, y, 0.0)
+        return np.where(rows, y, 0.0)
 
     def begin(self, tol, max_iter, precond):
         self.tol2, self.max_iter = tol * tol, max_iter
         self.it, self.done = 0, 0
-        self.r = np.where(self.own, self.rhs, 0.0)
+        self.ra[...] = np.where(self.own, self.rhs, 0.0)
         self.inv = np.where(self.own & (self.diag != 0), 1.0 / np.where(self.diag != 0, self.diag, 1.0), 0.0)
-        self.za[...] = self.inv * self.r
+        self.za[...] = self.inv * self.ra
         self.xa[...] = 0.0
         self.p = np.zeros(self.shape)
         self.sums[:] = 0
-        self.sums[0], self.sums[1] = float((self.r * self.r).sum()), float((self.r * self.za).sum())
+        self.sums[0], self.sums[1] = float((self.ra * self.ra).sum()), float((self.ra * self.za).sum())
+
+    def precondition(self):
+        if self.done:
+            return
+        inv = np.where(self.region & (self.diag != 0), 1.0 / np.where(self.diag != 0, self.diag, 1.0), 0.0)
+        t = inv * np.where(self.region, self.ra, 0.0)
+        self.za[...] = 2.0 * t - inv * self._apply(t, self.region)
+
+    def combine(self):
+        if self.done:
+            return
+        m = self.overlap
+        if self._ex.g_lo:
+            sl = slice(self.k0 - 1, self.k0 + m)
+            self.za[sl] += np.where(self.region[sl], self.recv_lo, 0.0)
+        if self._ex.g_hi:
+            sl = slice(self.k1 - m, self.k1 + 1)
+            self.za[sl] += np.where(self.region[sl], self.recv_hi, 0.0)
+        r = np.where(self.own, self.ra, 0.0)
+        self.sums[:] = 0
+        self.sums[0], self.sums[1] = float((r * r).sum()), float((r * self.za).sum())
 
     def direction(self):
         if self.done:
@@ -125,10 +166,10 @@ class NumpySlabSolver:
             return
         alpha = self.rz_prev / float(self.sums[2])
         self.xa += alpha * np.where(self.own, self.p, 0.0)
-        self.r = self.r - alpha * self.ap
-        self.za[...] = self.inv * self.r
+        self.ra[...] = np.where(self.own, self.ra - alpha * self.ap, 0.0)
+        self.za[...] = self.inv * self.ra
         self.sums[:] = 0
-        self.sums[0], self.sums[1] = float((self.r * self.r).sum()), float((self.r * self.za).sum())
+        self.sums[0], self.sums[1] = float((self.ra * self.ra).sum()), float((self.ra * self.za).sum())
         self.it += 1
 
     def status(self):
@@ -138,7 +179,7 @@ class NumpySlabSolver:
         return {"converged": int(self.done == 1), "iterations": self.it}
 
 
-def _cpu_worker(rank, port, out_dir):
+def _cpu_worker(rank, port, out_dir, overlap):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -158,7 +199,7 @@ def _cpu_worker(rank, port, out_dir):
         assert np.array_equal(label[k0:k1], g_label[o0:o1])
         assert np.array_equal(diag[k0:k1], g_diag[o0:o1]) and np.array_equal(rhs[k0:k1], g_rhs[o0:o1])
         assert np.array_equal(off[:, k0:k1], g_off[:, o0:o1])
-        solver = NumpySlabSolver(layout, rank, label, off, diag, rhs)
+        solver = NumpySlabSolver(layout, rank, label, off, diag, rhs, overlap=overlap)
         info = slab_pcg_solve(solver, Comm(), 1e-13, 5000, 0, check_every=4)
         assert info["converged"] == 1
         # after exchange_x the ghost planes hold the neighbour's solution
@@ -196,11 +237,12 @@ def test_slab_layout_and_partition():
         assert (~p.owned).sum() > 0                                       # ghost copies are present
 
 
-def test_two_rank_slab_solve_matches_the_global_solve(tmp_path):
+@pytest.mark.parametrize("overlap", [0, 3])
+def test_two_rank_slab_solve_matches_the_global_solve(tmp_path, overlap):
     import torch.multiprocessing as mp
     from oracle import Oracle
     port = _free_port()
-    mp.spawn(_cpu_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    mp.spawn(_cpu_worker, args=(port, str(tmp_path), overlap), nprocs=WORLD, join=True)
     sc = _scene()
     o = Oracle(sc.desc(), threads=2)
     label, off, diag, rhs = _assemble(o, sc, 0.004)
@@ -227,8 +269,12 @@ def test_two_rank_slab_solve_matches_the_global_solve(tmp_path):
         # ghost planes: the neighbour's values arrived
         assert np.allclose(x, single.xa[e0:e1], rtol=0, atol=1e-9 * np.abs(single.xa).max())
     assert its[0] == its[1]
-    # with point Jacobi the slab iteration is the global iteration up to summation order
-    assert abs(its[0] - info["iterations"]) <= 2
+    if overlap == 0:
+        # with point Jacobi the slab iteration is the global iteration up to summation order
+        assert abs(its[0] - info["iterations"]) <= 2
+    else:
+        # the overlapping preconditioner is stronger than point Jacobi
+        assert its[0] < info["iterations"]
     assert np.abs(joined - single.xa).max() <= 1e-9 * np.abs(single.xa).max()
     # and it solves the system: residual of the joined vector under the global operator
     res = np.where(label > 0, rhs - single._apply(joined), 0.0)
@@ -238,7 +284,7 @@ def test_two_rank_slab_solve_matches_the_global_solve(tmp_path):
 # ------------------------------------------------------------------------------------------------
 # GPU: two ranks on the one device of the box, real kernels, gloo with host staging
 
-def _gpu_worker(rank, port, out_dir, precond, kind):
+def _gpu_worker(rank, port, out_dir, precond, kind, overlap):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -247,7 +293,7 @@ def _gpu_worker(rank, port, out_dir, precond, kind):
     from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout, partition_scene
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=WORLD)
     try:
-        _gpu_rank_body(rank, out_dir, precond, kind)
+        _gpu_rank_body(rank, out_dir, precond, kind, overlap)
     except BaseException:
         import traceback
         with open(os.path.join(out_dir, f"error_{rank}.txt"), "w") as f:
@@ -257,7 +303,7 @@ def _gpu_worker(rank, port, out_dir, precond, kind):
         dist.destroy_process_group()
 
 
-def _gpu_rank_body(rank, out_dir, precond, kind):
+def _gpu_rank_body(rank, out_dir, precond, kind, overlap):
     import torch
     from fluidsimulation_amd import FlipContext
     from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout, partition_scene
@@ -269,7 +315,7 @@ def _gpu_rank_body(rank, out_dir, precond, kind):
         with FlipContext(loc.desc(), device=0) as ctx:
             ctx.reserve_particles(2 * loc.pos.shape[0])
             ctx.upload_scene(loc)
-            step = DistributedSubstep(ctx, layout, Comm(), device=0, precond=precond, max_iter=20000)
+            step = DistributedSubstep(ctx, layout, Comm(), device=0, precond=precond, max_iter=20000, overlap=overlap)
             info = step.step(0.004)
             p = ctx.download("pressure")
             # after the exchange the set holds this rank's owned particles and fresh ghost copies
@@ -284,7 +330,8 @@ def _gpu_rank_body(rank, out_dir, precond, kind):
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), pos=pos[owned1], vel=vel[owned1], pos2=pos2[owned2], vel2=vel2[owned2],
                  n_ghost=int((~owned1).sum()), sent=np.array(info["exchange"]["sent"]),
                  conv=info["divergence"]["converged"] * info["density"]["converged"]
-                 * info2["divergence"]["converged"] * info2["density"]["converged"], p=p)
+                 * info2["divergence"]["converged"] * info2["density"]["converged"], p=p,
+                 iterations=info["divergence"]["iterations"])
 
 
 def _scene_gpu(kind="dam"):
@@ -300,14 +347,14 @@ def _scene_gpu(kind="dam"):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precond,kind", [(0, "dam"), (1, "dam"), (1, "long")])
-def test_two_ranks_on_one_gpu_match_the_single_context_substep(tmp_path, precond, kind):
+@pytest.mark.parametrize("precond,kind,overlap", [(0, "dam", 0), (1, "dam", 0), (1, "long", 0), (1, "dam", 8), (1, "long", 5), (0, "dam", 2)])
+def test_two_ranks_on_one_gpu_match_the_single_context_substep(tmp_path, precond, kind, overlap):
     import torch.multiprocessing as mp
     from fluidsimulation_amd import FlipContext, FlipSubstep
     from fluidsimulation_amd.distributed import SlabLayout
     port = _free_port()
     try:
-        mp.spawn(_gpu_worker, args=(port, str(tmp_path), precond, kind), nprocs=WORLD, join=True)
+        mp.spawn(_gpu_worker, args=(port, str(tmp_path), precond, kind, overlap), nprocs=WORLD, join=True)
     except Exception:
         for r in range(WORLD):
             f = os.path.join(str(tmp_path), f"error_{r}.txt")
