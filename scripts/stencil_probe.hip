@@ -1,0 +1,223 @@
+// Tuning aid: times variants of the fused direction + SpMV kernel on a synthetic liquid block, to find what bounds
+// the row-list stencil kernels of the solver.  Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o stencil_probe stencil_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define BLK 256
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Args {
+    long long n, sy, sz;
+    int nblk;
+    double beta, s2;
+    const int32_t *rows;
+    const double *z, *pold, *diag;
+    const float *cx, *cy, *cz;
+    double *pnew, *ap, *partial;
+};
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+__device__ __forceinline__ void row_range(const Args &A, long long &lo, long long &hi) {
+    const int per = A.nblk >> 3;
+    const int rank = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    lo = (A.n * rank) / A.nblk;
+    hi = (A.n * (rank + 1)) / A.nblk;
+}
+#define BODY(c)                                                                                                            \
+    {                                                                                                                      \
+        const double z0 = z[c], zxm = z[c - 1], zxp = z[c + 1], zym = z[c - sy], zyp = z[c + sy], zzm = z[c - sz],         \
+                     zzp = z[c + sz];                                                                                      \
+        const double p0 = pold[c], pxm = pold[c - 1], pxp = pold[c + 1], pym = pold[c - sy], pyp = pold[c + sy],           \
+                     pzm = pold[c - sz], pzp = pold[c + sz];                                                               \
+        const float axm = cx[c], axp = cx[c + 1], aym = cy[c], ayp = cy[c + sy], azm = cz[c], azp = cz[c + sz];            \
+        const double d = dg[c];                                                                                            \
+        const double pc = z0 + beta * p0;                                                                                  \
+        double acc = (double)axm * (zxm + beta * pxm);                                                                     \
+        acc += (double)axp * (zxp + beta * pxp);                                                                           \
+        acc += (double)aym * (zym + beta * pym);                                                                           \
+        acc += (double)ayp * (zyp + beta * pyp);                                                                           \
+        acc += (double)azm * (zzm + beta * pzm);                                                                           \
+        acc += (double)azp * (zzp + beta * pzp);                                                                           \
+        const double s = d * pc - A.s2 * acc;                                                                              \
+        A.pnew[c] = pc;                                                                                                    \
+        A.ap[c] = s;                                                                                                       \
+        pap += pc * s;                                                                                                     \
+    }
+#define PROLOGUE                                                                                                           \
+    __shared__ double scratch[4];                                                                                          \
+    const double *__restrict__ z = A.z, *__restrict__ pold = A.pold, *__restrict__ dg = A.diag;                            \
+    const float *__restrict__ cx = A.cx, *__restrict__ cy = A.cy, *__restrict__ cz = A.cz;                                 \
+    const long long sy = A.sy, sz = A.sz;                                                                                  \
+    const double beta = A.beta;                                                                                            \
+    long long lo, hi;                                                                                                      \
+    row_range(A, lo, hi);                                                                                                  \
+    double pap = 0.0;
+#define EPILOGUE                                                                                                           \
+    pap = block_sum(pap, scratch);                                                                                         \
+    if (threadIdx.x == 0) A.partial[blockIdx.x] = pap;
+
+// K0: the production form
+__global__ void __launch_bounds__(BLK) k0(Args A) {
+    PROLOGUE
+#pragma unroll 2
+    for (long long q = lo + threadIdx.x; q < hi; q += BLK) {
+        const long long c = A.rows[q];
+        BODY(c)
+    }
+    EPILOGUE
+}
+// K1: row index of the next trip loaded before the current one is processed
+__global__ void __launch_bounds__(BLK) k1(Args A) {
+    PROLOGUE
+    long long q = lo + threadIdx.x;
+    int cn = q < hi ? A.rows[q] : 0;
+    for (; q < hi; q += BLK) {
+        const long long c = cn;
+        if (q + BLK < hi) cn = A.rows[q + BLK];
+        BODY(c)
+    }
+    EPILOGUE
+}
+// K2: SpMV only (7 loads of one vector): what the gathers of the second vector cost
+__global__ void __launch_bounds__(BLK) k2(Args A) {
+    PROLOGUE
+    (void)pold; (void)beta;
+#pragma unroll 2
+    for (long long q = lo + threadIdx.x; q < hi; q += BLK) {
+        const long long c = A.rows[q];
+        const double z0 = z[c], zxm = z[c - 1], zxp = z[c + 1], zym = z[c - sy], zyp = z[c + sy], zzm = z[c - sz], zzp = z[c + sz];
+        const float axm = cx[c], axp = cx[c + 1], aym = cy[c], ayp = cy[c + sy], azm = cz[c], azp = cz[c + sz];
+        double acc = (double)axm * zxm;
+        acc += (double)axp * zxp; acc += (double)aym * zym; acc += (double)ayp * zyp; acc += (double)azm * zzm; acc += (double)azp * zzp;
+        const double s = dg[c] * z0 - A.s2 * acc;
+        A.pnew[c] = z0;
+        A.ap[c] = s;
+        pap += z0 * s;
+    }
+    EPILOGUE
+}
+// K3: 32-bit cell ids and strides
+__global__ void __launch_bounds__(BLK) k3(Args A) {
+    __shared__ double scratch[4];
+    const double *__restrict__ z = A.z, *__restrict__ pold = A.pold, *__restrict__ dg = A.diag;
+    const float *__restrict__ cx = A.cx, *__restrict__ cy = A.cy, *__restrict__ cz = A.cz;
+    const int sy = (int)A.sy, sz = (int)A.sz;
+    const double beta = A.beta;
+    long long lo, hi;
+    row_range(A, lo, hi);
+    double pap = 0.0;
+    const int n = (int)(hi - lo);
+    const int32_t *__restrict__ rows = A.rows + lo;
+#pragma unroll 2
+    for (int q = threadIdx.x; q < n; q += BLK) {
+        const int c = rows[q];
+        BODY(c)
+    }
+    EPILOGUE
+}
+// K4: streaming floor: own-cell loads only (z, p, diag, 3 couplings), same stores
+__global__ void __launch_bounds__(BLK) k4(Args A) {
+    PROLOGUE
+#pragma unroll 2
+    for (long long q = lo + threadIdx.x; q < hi; q += BLK) {
+        const long long c = A.rows[q];
+        const double pc = z[c] + beta * pold[c];
+        const double s = dg[c] * pc - A.s2 * ((double)cx[c] + (double)cy[c] + (double)cz[c]);
+        A.pnew[c] = pc;
+        A.ap[c] = s;
+        pap += pc * s;
+    }
+    (void)sy; (void)sz;
+    EPILOGUE
+}
+// K5: x neighbours from the neighbouring lanes when the list is contiguous there
+__global__ void __launch_bounds__(BLK) k5(Args A) {
+    PROLOGUE
+#pragma unroll 2
+    for (long long q0 = lo; q0 < hi; q0 += BLK) {
+        const long long q = q0 + threadIdx.x;
+        const bool live = q < hi;
+        const int c = live ? A.rows[q] : -2;
+        double pc = 0.0;
+        if (live) pc = z[c] + beta * pold[c];
+        const int cl = __shfl_up(c, 1, 64), cr = __shfl_down(c, 1, 64);
+        double pl = __shfl_up(pc, 1, 64), pr = __shfl_down(pc, 1, 64);
+        const int lane = threadIdx.x & 63;
+        if (live) {
+            if (lane == 0 || cl != c - 1) pl = z[c - 1] + beta * pold[c - 1];
+            if (lane == 63 || cr != c + 1) pr = z[c + 1] + beta * pold[c + 1];
+            const double zym = z[c - sy], zyp = z[c + sy], zzm = z[c - sz], zzp = z[c + sz];
+            const double pym = pold[c - sy], pyp = pold[c + sy], pzm = pold[c - sz], pzp = pold[c + sz];
+            const float axm = cx[c], axp = cx[c + 1], aym = cy[c], ayp = cy[c + sy], azm = cz[c], azp = cz[c + sz];
+            double acc = (double)axm * pl;
+            acc += (double)axp * pr;
+            acc += (double)aym * (zym + beta * pym);
+            acc += (double)ayp * (zyp + beta * pyp);
+            acc += (double)azm * (zzm + beta * pzm);
+            acc += (double)azp * (zzp + beta * pzp);
+            const double s = dg[c] * pc - A.s2 * acc;
+            A.pnew[c] = pc;
+            A.ap[c] = s;
+            pap += pc * s;
+        }
+    }
+    EPILOGUE
+}
+
+template <class K>
+static void run(const char *name, K kern, Args A, int nblk, double bytes) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int w = 0; w < 5; ++w) kern<<<nblk, BLK>>>(A);
+    CK(hipDeviceSynchronize());
+    const int reps = 200;
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) kern<<<nblk, BLK>>>(A);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps;
+    printf("%-28s nblk %5d  %8.2f us  %6.2f TB/s (53 B/row)\n", name, nblk, us, bytes / us * 1e-6);
+}
+
+int main(int argc, char **argv) {
+    const int scale = argc > 1 ? atoi(argv[1]) : 1;   // 1: 256^3-like, 2: 512^3-like
+    const int nx = 160 * scale, ny = 200 * scale, nz = 160 * scale;
+    const int lx = 128 * scale, ly = 94 * scale, lz = 128 * scale;
+    const long long B = (long long)nx * ny * nz, sy = nx, sz = (long long)nx * ny, pad = sz + 256;
+    std::vector<int32_t> rows;
+    for (int k = 1; k <= lz; ++k) for (int j = 1; j <= ly; ++j) for (int i = 1; i <= lx; ++i) rows.push_back((int32_t)(i + sy * j + sz * k));
+    const long long n = (long long)rows.size();
+    printf("box %d x %d x %d = %lld cells, %lld rows\n", nx, ny, nz, B, n);
+    auto dalloc = [&](size_t bytes) { void *p; CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0, bytes)); return p; };
+    double *z = (double *)dalloc((B + 2 * pad) * 8) + pad, *pold = (double *)dalloc((B + 2 * pad) * 8) + pad;
+    double *pnew = (double *)dalloc((B + 2 * pad) * 8) + pad, *ap = (double *)dalloc((B + 2 * pad) * 8) + pad;
+    double *dg = (double *)dalloc((B + 2 * pad) * 8) + pad;
+    float *cx = (float *)dalloc((B + 2 * pad) * 4) + pad, *cy = (float *)dalloc((B + 2 * pad) * 4) + pad, *cz = (float *)dalloc((B + 2 * pad) * 4) + pad;
+    int32_t *drows = (int32_t *)dalloc(n * 4);
+    CK(hipMemcpy(drows, rows.data(), n * 4, hipMemcpyHostToDevice));
+    std::vector<double> hz(B);
+    for (long long c = 0; c < B; ++c) hz[c] = (double)((c * 2654435761u) % 1000) * 1e-3;
+    CK(hipMemcpy(z, hz.data(), B * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(pold, hz.data(), B * 8, hipMemcpyHostToDevice));
+    double *partial = (double *)dalloc(4096 * 8);
+    Args A{ n, sy, sz, 1024, 0.37, 1.0, drows, z, pold, dg, cx, cy, cz, pnew, ap, partial };
+    const double bytes = 53.0 * (double)n;
+    for (int nblk : { 1024, 1280, 2048 }) {
+        A.nblk = nblk;
+        run("k0 production", k0, A, nblk, bytes);
+        run("k1 index prefetch", k1, A, nblk, bytes);
+        run("k2 spmv only (7 loads)", k2, A, nblk, bytes);
+        run("k3 32-bit ids", k3, A, nblk, bytes);
+        run("k4 own cell only", k4, A, nblk, bytes);
+        run("k5 x neighbours by shuffle", k5, A, nblk, bytes);
+    }
+    return 0;
+}
