@@ -1,6 +1,8 @@
 // flip_ctx.hip -- context life cycle, dense-field and particle transfers, the integer scan.
 #include "flip_internal.h"
 
+#include <utility>
+
 #include <algorithm>
 
 static std::string g_create_error;
@@ -48,23 +50,37 @@ static void free_particles(flip_ctx *c) {
     c->cap = 0;
 }
 
-extern "C" void flip_ctx_destroy(flip_ctx *c) {
-    if (!c) return;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    free_particles(c);
-    flip_mg_free(c);
-    dfree(c->cell_start); dfree(c->cell_fill); dfree(c->scan_tmp);
-    dfree(c->phi_fluid); dfree(c->phi_solid); dfree(c->phi_obj);
-    for (int b = 0; b < 4; ++b)
-        for (int a = 0; a < 3; ++a) dfree(c->vel[b][a]);
-    for (int a = 0; a < 3; ++a) {
-        dfree(c->disp[a]); dfree(c->wgt[a]); dfree(c->fwgt[a]); dfree(c->owgt[a]); dfree(c->term[a]);
-        dfree(c->valid[0][a]); dfree(c->valid[1][a]);
+// The arrays of one assembled system and its solve, allocated into the context's active fields.
+int flip_alloc_system(flip_ctx *c) {
+    flip_ctx *ctx = c;
+    const int64_t B = c->B;
+    hipError_t e = hipSuccess;
+#define A(ptr, count)                                  \
+    if (e == hipSuccess) e = dalloc(&(ptr), (count));
+    for (int a = 0; a < 3; ++a) A(c->term[a], B)
+    A(c->flags, B) A(c->diag, B) A(c->invdiag, B) A(c->rhs, B)
+    {
+        double **dp[] = { &c->x, &c->r, &c->z, &c->pv[0], &c->pv[1], &c->ap, &c->cg_diag, &c->cg_inv };
+        for (double **q : dp) {
+            A(*q, B + 2 * c->pad)
+            if (e == hipSuccess) *q += c->pad;
+        }
+        for (int a = 0; a < 3; ++a) {
+            A(c->cg_c[a], B + 2 * c->pad)
+            if (e == hipSuccess) c->cg_c[a] += c->pad;
+        }
     }
-    for (int a = 0; a < 6; ++a) dfree(c->J[a]);
-    dfree(c->density); dfree(c->active); dfree(c->active_back); dfree(c->label); dfree(c->band);
-    dfree(c->seed); dfree(c->tmp_u8); dfree(c->row_index);
+    A(c->cg_rows, B)
+    A(c->chunk_flag, c->n_chunks + 1) A(c->chunk_list, c->n_chunks + 1)
+    A(c->d_counts, 8) A(c->partial, 16 * FLIP_MAX_PCG_BLOCKS) A(c->scal, 1)
+#undef A
+    if (e != hipSuccess) return flip_fail_hip(ctx, e, "hipMalloc of the system arrays", __FILE__, __LINE__);
+    return 0;
+}
+
+void flip_free_system(flip_ctx *c) {
+    flip_mg_free(c);
+    for (int a = 0; a < 3; ++a) dfree(c->term[a]);
     dfree(c->flags); dfree(c->diag); dfree(c->invdiag); dfree(c->rhs);
     {   // padded solver arrays: the stored pointers are offset by c->pad
         double **dp[] = { &c->x, &c->r, &c->z, &c->pv[0], &c->pv[1], &c->ap, &c->cg_diag, &c->cg_inv };
@@ -73,13 +89,59 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
         for (int a = 0; a < 3; ++a)
             if (c->cg_c[a]) { (void)hipFree(c->cg_c[a] - c->pad); c->cg_c[a] = nullptr; }
     }
-    dfree(c->cg_scan); dfree(c->cg_rows);
+    dfree(c->cg_rows);
     dfree(c->chunk_flag); dfree(c->chunk_list); dfree(c->d_counts); dfree(c->partial); dfree(c->scal);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    c->events.clear();
+    if (c->batch_exec) { (void)hipGraphExecDestroy(c->batch_exec); c->batch_exec = nullptr; }
+}
+
+void flip_swap_systems(flip_ctx *c) {
+    flip_system_set &o = c->other;
+    std::swap(c->sys_kind, o.sys_kind); std::swap(c->sys_dt, o.sys_dt); std::swap(c->sys_s2, o.sys_s2);
+    std::swap(c->sys_coupled, o.sys_coupled); std::swap(c->sys_eliminated, o.sys_eliminated);
+    for (int a = 0; a < 3; ++a) { std::swap(c->term[a], o.term[a]); std::swap(c->cg_c[a], o.cg_c[a]); }
+    std::swap(c->flags, o.flags); std::swap(c->diag, o.diag); std::swap(c->invdiag, o.invdiag); std::swap(c->rhs, o.rhs);
+    std::swap(c->x, o.x); std::swap(c->r, o.r); std::swap(c->z, o.z); std::swap(c->pv[0], o.pv[0]); std::swap(c->pv[1], o.pv[1]);
+    std::swap(c->ap, o.ap); std::swap(c->cg_diag, o.cg_diag); std::swap(c->cg_inv, o.cg_inv);
+    std::swap(c->cg_rows, o.cg_rows); std::swap(c->chunk_flag, o.chunk_flag); std::swap(c->chunk_list, o.chunk_list);
+    std::swap(c->d_counts, o.d_counts); std::swap(c->n_active_chunks, o.n_active_chunks);
+    std::swap(c->partial, o.partial); std::swap(c->scal, o.scal);
+    c->events.swap(o.events); c->mg.swap(o.mg);
+    std::swap(c->mg_diag_f, o.mg_diag_f); std::swap(c->mg_inv_f, o.mg_inv_f);
+    std::swap(c->batch_exec, o.batch_exec); std::swap(c->batch_key, o.batch_key);
+}
+
+extern "C" void flip_ctx_destroy(flip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_particles(c);
+    flip_free_system(c);
+    if (c->other.allocated) {
+        flip_swap_systems(c);
+        flip_free_system(c);
+    }
+    for (int q = 0; q < 2; ++q)
+        if (c->pair_stream[q]) (void)hipStreamDestroy(c->pair_stream[q]);
+    for (int q = 0; q < 3; ++q)
+        if (c->pair_event[q]) (void)hipEventDestroy(c->pair_event[q]);
+    dfree(c->cell_start); dfree(c->cell_fill); dfree(c->scan_tmp);
+    dfree(c->phi_fluid); dfree(c->phi_solid); dfree(c->phi_obj);
+    for (int b = 0; b < 4; ++b)
+        for (int a = 0; a < 3; ++a) dfree(c->vel[b][a]);
+    for (int a = 0; a < 3; ++a) {
+        dfree(c->disp[a]); dfree(c->wgt[a]); dfree(c->fwgt[a]); dfree(c->owgt[a]);
+        dfree(c->valid[0][a]); dfree(c->valid[1][a]);
+    }
+    for (int a = 0; a < 6; ++a) dfree(c->J[a]);
+    dfree(c->density); dfree(c->active); dfree(c->active_back); dfree(c->label); dfree(c->band);
+    dfree(c->seed); dfree(c->tmp_u8); dfree(c->row_index);
+    dfree(c->cg_scan);
     if (c->mg_cz) (void)hipFree(c->mg_cz - c->pad);
     dfree(c->dist_sums); dfree(c->mg_rows); dfree(c->dist_recv[0]); dfree(c->dist_recv[1]);
     if (c->dist_rw) (void)hipFree(c->dist_rw - c->pad);
     dfree(c->d_vmax);
-    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -111,30 +173,20 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     for (int b = 0; b < 4; ++b)
         for (int a = 0; a < 3; ++a) A(c->vel[b][a], B)
     for (int a = 0; a < 3; ++a) {
-        A(c->disp[a], B) A(c->wgt[a], B) A(c->fwgt[a], B) A(c->owgt[a], B) A(c->term[a], B)
+        A(c->disp[a], B) A(c->wgt[a], B) A(c->fwgt[a], B) A(c->owgt[a], B)
         A(c->valid[0][a], B) A(c->valid[1][a], B)
     }
     for (int a = 0; a < 6; ++a) A(c->J[a], B)
     A(c->density, B) A(c->active, B) A(c->active_back, B) A(c->label, B) A(c->band, B) A(c->seed, B)
     A(c->tmp_u8, B) A(c->row_index, B + 1)
-    A(c->flags, B) A(c->diag, B) A(c->invdiag, B) A(c->rhs, B)
     {
         const int64_t plane = (int64_t)desc->nx * desc->ny;
         c->pad = ((plane + FLIP_BLOCK + 63) / 64) * 64;
-        double **dp[] = { &c->x, &c->r, &c->z, &c->pv[0], &c->pv[1], &c->ap, &c->cg_diag, &c->cg_inv };
-        for (double **q : dp) {
-            A(*q, B + 2 * c->pad)
-            if (e == hipSuccess) *q += c->pad;
-        }
-        for (int a = 0; a < 3; ++a) {
-            A(c->cg_c[a], B + 2 * c->pad)
-            if (e == hipSuccess) c->cg_c[a] += c->pad;
-        }
     }
-    A(c->cg_scan, B + 1) A(c->cg_rows, B)
-    A(c->chunk_flag, c->n_chunks + 1) A(c->chunk_list, c->n_chunks + 1)
-    A(c->d_counts, 8) A(c->partial, 16 * FLIP_MAX_PCG_BLOCKS) A(c->scal, 1) A(c->d_vmax, 3 * FLIP_MAX_PCG_BLOCKS)
+    A(c->cg_scan, B + 1)
+    A(c->d_vmax, 3 * FLIP_MAX_PCG_BLOCKS)
 #undef A
+    if (e == hipSuccess && flip_alloc_system(c) != 0) e = hipErrorOutOfMemory;
     if (e != hipSuccess) {
         flip_ctx_destroy(c);
         return flip_fail_hip(nullptr, e, "hipMalloc of the dense fields", __FILE__, __LINE__);

@@ -65,6 +65,32 @@ struct flip_mg_level {
     int32_t *rows = nullptr, *scan = nullptr, *n_rows = nullptr;
 };
 
+// The second assembled system of a context (flip_solve_pair keeps the divergence and the density system side by
+// side and iterates on both at once).  Field for field what flip_ctx holds for its active system; flip_swap_systems
+// exchanges the two sets, so every kernel wrapper keeps reading the context's own fields.
+struct flip_system_set {
+    int sys_kind = -1;
+    float sys_dt = 0.f;
+    double sys_s2 = 1.0;
+    bool sys_coupled = false, sys_eliminated = false;
+    float *term[3] = {};
+    uint8_t *flags = nullptr;
+    double *diag = nullptr, *invdiag = nullptr, *rhs = nullptr;
+    double *x = nullptr, *r = nullptr, *z = nullptr, *pv[2] = {}, *ap = nullptr;
+    float *cg_c[3] = {};
+    double *cg_diag = nullptr, *cg_inv = nullptr;
+    int32_t *cg_rows = nullptr, *chunk_flag = nullptr, *chunk_list = nullptr, *d_counts = nullptr;
+    int32_t n_active_chunks = 0;
+    double *partial = nullptr;
+    flip_pcg_scalars *scal = nullptr;
+    std::vector<hipEvent_t> events;
+    std::vector<flip_mg_level> mg;
+    float *mg_diag_f = nullptr, *mg_inv_f = nullptr;
+    hipGraphExec_t batch_exec = nullptr;
+    uint64_t batch_key = 0;
+    bool allocated = false;
+};
+
 struct flip_ctx {
     flip_grid_desc g;
     int64_t B = 0;       // cells in the box
@@ -143,6 +169,15 @@ struct flip_ctx {
     std::vector<hipEvent_t> events;
     std::vector<flip_mg_level> mg;  // coarse levels, finest first
     float *mg_diag_f = nullptr, *mg_inv_f = nullptr; // float copies of cg_diag / cg_inv for the V-cycle's level 0 (one allocation)
+    // one batch of solver iterations as an instantiated graph (the kernels' arguments do not change from solve to
+    // solve; batch_key says which arguments it was captured with)
+    hipGraphExec_t batch_exec = nullptr;
+    uint64_t batch_key = 0;
+
+    // ---- second system and the two streams of flip_solve_pair ----
+    flip_system_set other;
+    hipStream_t pair_stream[2] = { nullptr, nullptr };
+    hipEvent_t pair_event[3] = { nullptr, nullptr, nullptr };
 
     // ---- z-slab decomposition of the solve (flip_set_slab): rows of planes [slab_k0, slab_k1) belong to this
     // context, the other planes of the box are ghosts whose values a neighbouring rank supplies ----
@@ -162,6 +197,9 @@ struct flip_ctx {
     double *dist_rw = nullptr;      // weighted copy of the residual, the V-cycle's right-hand side when slab_weighted
 };
 
+int flip_alloc_system(flip_ctx *ctx);      // the active system's arrays (used for both sets)
+void flip_free_system(flip_ctx *ctx);
+void flip_swap_systems(flip_ctx *ctx);     // active <-> other
 int flip_mg_setup(flip_ctx *ctx);   // coarse operators of the assembled system
 int flip_mg_vcycle(flip_ctx *ctx);  // z = M^-1 r and the r.z partials
 void flip_mg_free(flip_ctx *ctx);

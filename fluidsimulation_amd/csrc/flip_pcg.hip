@@ -675,22 +675,38 @@ static void fill_pcg_args(flip_ctx *ctx, PcgArgs &A) {
     A.partial = ctx->partial;
     A.scal = ctx->scal;
     A.coupled = ctx->sys_coupled ? 1 : 0;
-    A.cdt = (double)ctx->sys_dt;
+    A.cdt = ctx->sys_coupled ? (double)ctx->sys_dt : 0.0; // read by the coupled kernels only
     for (int a = 0; a < 6; ++a) { A.minv[a] = ctx->obj_minv[a]; A.J[a] = ctx->J[a]; }
 }
 
-extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int precond, flip_pcg_info *info) {
-    FLIP_REQUIRE(ctx, "null context");
-    FLIP_REQUIRE(ctx->sys_kind >= 0, "flip_pcg_solve: call flip_build_system first");
-    FLIP_REQUIRE(precond == FLIP_PRECOND_JACOBI || precond == FLIP_PRECOND_MULTIGRID, "flip_pcg_solve: unknown preconditioner");
+// flip_pcg_solve in three parts, so that flip_solve_pair can interleave two solves:
+//   pcg_prepare  validation, scalars, zeroed vectors, coarse operators, r = b, z = M^-1 r
+//   pcg_batch    `batch` iterations (direction, update, V-cycle) enqueued on ctx->stream
+//   pcg_finish   dependent rows, counters, timings
+static int pair_streams(flip_ctx *ctx) {
+    for (int q = 0; q < 2; ++q)
+        if (!ctx->pair_stream[q]) FLIP_CHECK(hipStreamCreateWithFlags(&ctx->pair_stream[q], hipStreamNonBlocking));
+    for (int q = 0; q < 3; ++q)
+        if (!ctx->pair_event[q]) FLIP_CHECK(hipEventCreateWithFlags(&ctx->pair_event[q], hipEventDisableTiming));
+    return 0;
+}
+
+struct PcgRun {
+    bool use_mg = false, sym = false;
+    int n_prof = 0, launched = 0, max_iter = 0;
+};
+
+static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond, PcgRun &run, const char *who) {
+    FLIP_REQUIRE(ctx->sys_kind >= 0, "the solver needs flip_build_system first");
+    FLIP_REQUIRE(precond == FLIP_PRECOND_JACOBI || precond == FLIP_PRECOND_MULTIGRID, "unknown preconditioner");
     // the V-cycle is a symmetric operator for the symmetric CG system; a box too small to coarsen keeps Jacobi
     bool use_mg = precond == FLIP_PRECOND_MULTIGRID;
     FLIP_REQUIRE(!use_mg || ctx->sys_eliminated,
-                 "flip_pcg_solve: the multigrid preconditioner needs eliminate_dependent_rows = 1 (symmetric system)");
-    FLIP_REQUIRE(tol > 0.0, "flip_pcg_solve: tol must be positive");
-    FLIP_REQUIRE(!ctx->slab_on, "flip_pcg_solve: this context owns a slab of a larger system; use the flip_pcg_dist_* entry points");
-    FLIP_REQUIRE(ctx->pcg_blocks % 8 == 0 && ctx->pcg_blocks <= FLIP_MAX_PCG_BLOCKS, "flip_pcg_solve: bad grid size");
-    FLIP_CHECK(hipSetDevice(ctx->device));
+                 "the multigrid preconditioner needs eliminate_dependent_rows = 1 (symmetric system)");
+    FLIP_REQUIRE(tol > 0.0, "tol must be positive");
+    FLIP_REQUIRE(!ctx->slab_on, "this context owns a slab of a larger system; use the flip_pcg_dist_* entry points");
+    FLIP_REQUIRE(ctx->pcg_blocks % 8 == 0 && ctx->pcg_blocks <= FLIP_MAX_PCG_BLOCKS, "bad PCG grid size");
+    (void)who;
     hipStream_t st = ctx->stream;
     if (max_iter <= 0) max_iter = 2 * (ctx->n_rows > 0 ? ctx->n_rows : 1);
 
@@ -709,77 +725,255 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
         if (int rc = flip_mg_setup(ctx)) return rc;
         if (ctx->mg.empty()) use_mg = false;
     }
-
     PcgArgs A;
     fill_pcg_args(ctx, A);
-    const int nblk = ctx->pcg_blocks;
-
     while (ctx->events.size() < 2 + 2 * 64) {
         hipEvent_t e;
         FLIP_CHECK(hipEventCreate(&e));
         ctx->events.push_back(e);
     }
     FLIP_CHECK(hipEventRecord(ctx->events[0], st));
-    k_pcg_init<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+    k_pcg_init<<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(A);
     FLIP_LAUNCH_CHECK();
     if (use_mg)
         if (int rc = flip_mg_vcycle(ctx)) return rc;
+    run.use_mg = use_mg;
+    run.sym = ctx->sys_eliminated; // dependent rows eliminated -> symmetric CG system
+    run.n_prof = 0;
+    run.launched = 0;
+    run.max_iter = max_iter;
+    return 0;
+}
 
-    const int batch = use_mg ? 8 : 32;
-    const bool sym = ctx->sys_eliminated; // dependent rows eliminated -> symmetric CG system
-    int launched = 0, n_prof = 0;
-    int32_t done = 0;
-    // one extra direction launch decides convergence after the last update
-    while (!done && launched <= max_iter) {
-        for (int b = 0; b < batch; ++b) {
-            const bool prof = ctx->profiling && n_prof < 64;
-            if (prof) FLIP_CHECK(hipEventRecord(ctx->events[2 + 2 * n_prof], st));
-            if (sym) k_pcg_direction<true><<<nblk, FLIP_BLOCK, 0, st>>>(A);
-            else k_pcg_direction<false><<<nblk, FLIP_BLOCK, 0, st>>>(A);
-            if (prof) { FLIP_CHECK(hipEventRecord(ctx->events[3 + 2 * n_prof], st)); ++n_prof; }
-            k_pcg_update<<<nblk, FLIP_BLOCK, 0, st>>>(A);
-            if (use_mg)
-                if (int rc = flip_mg_vcycle(ctx)) return rc;
-        }
-        FLIP_LAUNCH_CHECK();
-        launched += batch;
-        FLIP_CHECK(hipMemcpyAsync(&done, &ctx->scal->done, 4, hipMemcpyDeviceToHost, st));
-        FLIP_CHECK(hipStreamSynchronize(st));
+static int pcg_batch_direct(flip_ctx *ctx, PcgRun &run, int batch, bool allow_events);
+
+static bool pcg_graphs_enabled() {
+    static const bool on = [] { const char *e = getenv("FLIP_GRAPHS"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
+// `batch` iterations on ctx->stream.  The launches of a batch take the same arguments in every solve of a kind (the
+// iteration's state lives in device memory), so they can be captured once into a graph and replayed.  That pays when
+// two solves share the device (flip_solve_pair): 2 x 19 launches per iteration pair cost more host time than the
+// device needs to run them.  A single solve is faster with plain launches (measured), and only those can be
+// bracketed by the profiling events.
+static int pcg_batch(flip_ctx *ctx, PcgRun &run, int batch, bool as_graph) {
+    hipStream_t st = ctx->stream;
+    if (!as_graph || !pcg_graphs_enabled() || ctx->sys_coupled || st == nullptr) return pcg_batch_direct(ctx, run, batch, ctx->profiling);
+    PcgArgs A;
+    fill_pcg_args(ctx, A);
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t q = 0; q < n; ++q) { key ^= b[q]; key *= 1099511628211ull; }
+    };
+    mix(&A, sizeof A);
+    const int extra[4] = { batch, run.use_mg ? 1 : 0, run.sym ? 1 : 0, (int)ctx->mg.size() };
+    mix(extra, sizeof extra);
+    mix(&ctx->mg_diag_f, sizeof ctx->mg_diag_f);
+    if (!ctx->batch_exec || ctx->batch_key != key) {
+        if (ctx->batch_exec) { FLIP_CHECK(hipGraphExecDestroy(ctx->batch_exec)); ctx->batch_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        FLIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        PcgRun scratch = run;
+        const int rc = pcg_batch_direct(ctx, scratch, batch, false);
+        const hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        FLIP_CHECK(e);
+        const hipError_t ei = hipGraphInstantiate(&ctx->batch_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        FLIP_CHECK(ei);
+        ctx->batch_key = key;
     }
+    FLIP_CHECK(hipGraphLaunch(ctx->batch_exec, st));
+    run.launched += batch;
+    return 0;
+}
+
+static int pcg_batch_direct(flip_ctx *ctx, PcgRun &run, int batch, bool allow_events) {
+    hipStream_t st = ctx->stream;
+    PcgArgs A;
+    fill_pcg_args(ctx, A);
+    const int nblk = ctx->pcg_blocks;
+    for (int b = 0; b < batch; ++b) {
+        const bool prof = allow_events && run.n_prof < 64;
+        if (prof) FLIP_CHECK(hipEventRecord(ctx->events[2 + 2 * run.n_prof], st));
+        if (run.sym) k_pcg_direction<true><<<nblk, FLIP_BLOCK, 0, st>>>(A);
+        else k_pcg_direction<false><<<nblk, FLIP_BLOCK, 0, st>>>(A);
+        if (prof) { FLIP_CHECK(hipEventRecord(ctx->events[3 + 2 * run.n_prof], st)); ++run.n_prof; }
+        k_pcg_update<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+        if (run.use_mg)
+            if (int rc = flip_mg_vcycle(ctx)) return rc;
+    }
+    FLIP_LAUNCH_CHECK();
+    run.launched += batch;
+    return 0;
+}
+
+// Enqueues the tail of a solve on ctx->stream: dependent rows, end event, read-back of scalars and counters into
+// host memory that must stay alive until the stream has been synchronised; pcg_report then fills `info`.
+struct PcgTail { flip_pcg_scalars h; int32_t counts[8]; };
+static int pcg_enqueue_tail(flip_ctx *ctx, PcgTail &t) {
+    hipStream_t st = ctx->stream;
+    PcgArgs A;
+    fill_pcg_args(ctx, A);
     if (ctx->sys_eliminated) {
-        k_pcg_dependent<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+        k_pcg_dependent<<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(A);
         FLIP_LAUNCH_CHECK();
     }
     FLIP_CHECK(hipEventRecord(ctx->events[1], st));
-    FLIP_CHECK(hipMemcpyAsync(&h, ctx->scal, sizeof h, hipMemcpyDeviceToHost, st));
-    int32_t counts[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    FLIP_CHECK(hipMemcpyAsync(counts, ctx->d_counts, 32, hipMemcpyDeviceToHost, st));
-    FLIP_CHECK(hipStreamSynchronize(st));
-    ctx->n_active_chunks = counts[1];
-    if (info) {
-        memset(info, 0, sizeof *info);
-        info->converged = h.done == 1 ? 1 : 0;
-        info->iterations = h.it_a;
-        info->rows = counts[0];
-        info->active_chunks = counts[1];
-        info->dependent_rows = counts[4];
-        info->cg_rows = counts[6];
-        info->rhs_norm_2 = sqrt(h.rhs_norm2);
-        info->rel_residual_2 = h.rhs_norm2 > 0 ? sqrt(h.rr / h.rhs_norm2) : 0.0;
-        float ms = 0.f;
-        FLIP_CHECK(hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]));
-        info->seconds = (double)ms * 1e-3;
-        double sp = 0.0;
-        int used = 0;
-        for (int q = 0; q < n_prof && q < h.it_a; ++q) {
-            float t = 0.f;
-            FLIP_CHECK(hipEventElapsedTime(&t, ctx->events[2 + 2 * q], ctx->events[3 + 2 * q]));
-            sp += (double)t * 1e-3;
-            ++used;
-        }
-        info->spmv_seconds = sp;
-        info->spmv_launches = used;
+    memset(&t, 0, sizeof t);
+    FLIP_CHECK(hipMemcpyAsync(&t.h, ctx->scal, sizeof t.h, hipMemcpyDeviceToHost, st));
+    FLIP_CHECK(hipMemcpyAsync(t.counts, ctx->d_counts, 32, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+static int pcg_report(flip_ctx *ctx, const PcgRun &run, const PcgTail &t, flip_pcg_info *info) {
+    ctx->n_active_chunks = t.counts[1];
+    if (!info) return 0;
+    memset(info, 0, sizeof *info);
+    info->converged = t.h.done == 1 ? 1 : 0;
+    info->iterations = t.h.it_a;
+    info->rows = t.counts[0];
+    info->active_chunks = t.counts[1];
+    info->dependent_rows = t.counts[4];
+    info->cg_rows = t.counts[6];
+    info->rhs_norm_2 = sqrt(t.h.rhs_norm2);
+    info->rel_residual_2 = t.h.rhs_norm2 > 0 ? sqrt(t.h.rr / t.h.rhs_norm2) : 0.0;
+    float ms = 0.f;
+    FLIP_CHECK(hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]));
+    info->seconds = (double)ms * 1e-3;
+    double sp = 0.0;
+    int used = 0;
+    for (int q = 0; q < run.n_prof && q < t.h.it_a; ++q) {
+        float e = 0.f;
+        FLIP_CHECK(hipEventElapsedTime(&e, ctx->events[2 + 2 * q], ctx->events[3 + 2 * q]));
+        sp += (double)e * 1e-3;
+        ++used;
     }
+    info->spmv_seconds = sp;
+    info->spmv_launches = used;
+    return 0;
+}
+
+extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int precond, flip_pcg_info *info) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    PcgRun run;
+    if (int rc = pcg_prepare(ctx, tol, max_iter, precond, run, "flip_pcg_solve")) return rc;
+    // the iterations run on a stream of the library's own (the caller's may be the null stream, which cannot be
+    // captured into a graph), ordered after everything enqueued so far
+    hipStream_t main_stream = ctx->stream;
+    if (int rc = pair_streams(ctx)) return rc;
+    hipStream_t st = ctx->pair_stream[0];
+    FLIP_CHECK(hipEventRecord(ctx->pair_event[2], main_stream));
+    FLIP_CHECK(hipStreamWaitEvent(st, ctx->pair_event[2], 0));
+    ctx->stream = st;
+    const int batch = run.use_mg ? 8 : 32;
+    int32_t done = 0;
+    int rc = 0;
+    // one extra direction launch decides convergence after the last update
+    while (!rc && !done && run.launched <= run.max_iter) {
+        rc = pcg_batch(ctx, run, batch, false);
+        if (!rc && hipMemcpyAsync(&done, &ctx->scal->done, 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = flip_fail(ctx, "hipMemcpyAsync of the stop flag", __FILE__, __LINE__);
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = flip_fail(ctx, "hipStreamSynchronize in the solver loop", __FILE__, __LINE__);
+    }
+    PcgTail tail;
+    if (!rc) rc = pcg_enqueue_tail(ctx, tail);
+    ctx->stream = main_stream;
+    if (rc) return rc;
+    FLIP_CHECK(hipStreamSynchronize(st));
+    FLIP_CHECK(hipEventRecord(ctx->pair_event[0], st));
+    FLIP_CHECK(hipStreamWaitEvent(main_stream, ctx->pair_event[0], 0));
+    return pcg_report(ctx, run, tail, info);
+}
+
+// The divergence system (src/FluidSimulator.cpp:505) and the density system (:521) of one substep depend on the same
+// labels, level sets and face fractions and on nothing the other solve produces, so both are assembled first and then
+// iterated side by side on two streams: the latency-bound coarse levels of one V-cycle run under the bandwidth-bound
+// fine level of the other.  Each solve performs exactly the operations flip_build_system + flip_pcg_solve would.
+// Afterwards the divergence system is the active one; flip_select_system switches between the two for the projections.
+extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_iter, int precond, flip_pcg_info *info_divergence,
+                               flip_pcg_info *info_density) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(!ctx->slab_on, "flip_solve_pair: not available on a slab context");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t main_stream = ctx->stream;
+    if (int rc0 = pair_streams(ctx)) return rc0;
+    if (!ctx->other.allocated) {
+        flip_swap_systems(ctx);
+        const int rc = flip_alloc_system(ctx);
+        flip_swap_systems(ctx);
+        if (rc) return rc;
+        ctx->other.allocated = true;
+    }
+    // make the density system the other set and the divergence system the active one
+    PcgRun run[2];
+    int rc = 0;
+    flip_swap_systems(ctx);
+    FLIP_CHECK(hipMemcpyAsync(ctx->d_counts, ctx->other.d_counts, 4, hipMemcpyDeviceToDevice, main_stream)); // rows of index_cells
+    rc = flip_build_system(ctx, FLIP_SOLVE_DENSITY, dt);
+    if (!rc) rc = pcg_prepare(ctx, tol, max_iter, precond, run[1], "flip_solve_pair");
+    flip_swap_systems(ctx);
+    if (rc) return rc;
+    if ((rc = flip_build_system(ctx, FLIP_SOLVE_DIVERGENCE, dt))) return rc;
+    if ((rc = pcg_prepare(ctx, tol, max_iter, precond, run[0], "flip_solve_pair"))) return rc;
+    // both solve streams start after everything enqueued so far
+    FLIP_CHECK(hipEventRecord(ctx->pair_event[2], main_stream));
+    FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[0], ctx->pair_event[2], 0));
+    FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[1], ctx->pair_event[2], 0));
+    int32_t done[2] = { 0, 0 };
+    bool active[2] = { true, true };
+    // from here on ctx->stream is the stream of whichever system is active; restored before returning
+    auto with_system = [&](int q, auto &&fn) -> int {
+        if (q == 1) flip_swap_systems(ctx);
+        ctx->stream = ctx->pair_stream[q];
+        const int r = fn();
+        ctx->stream = main_stream;
+        if (q == 1) flip_swap_systems(ctx);
+        return r;
+    };
+    if (ctx->profiling) {
+        // the direction kernels bracketed by events run with the device to themselves: two iterations of the divergence
+        // solve before the density solve's stream is released
+        if ((rc = with_system(0, [&] { return pcg_batch_direct(ctx, run[0], 2, true); }))) return rc;
+        FLIP_CHECK(hipEventRecord(ctx->pair_event[2], ctx->pair_stream[0]));
+        FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[1], ctx->pair_event[2], 0));
+    }
+    while (active[0] || active[1]) {
+        for (int q = 0; q < 2; ++q)
+            if (active[q])
+                if ((rc = with_system(q, [&] { return pcg_batch(ctx, run[q], run[q].use_mg ? 8 : 32, true); }))) return rc;
+        for (int q = 0; q < 2; ++q)
+            if (active[q]) {
+                const flip_pcg_scalars *sc = q == 0 ? ctx->scal : ctx->other.scal;
+                FLIP_CHECK(hipMemcpyAsync(&done[q], &sc->done, 4, hipMemcpyDeviceToHost, ctx->pair_stream[q]));
+            }
+        for (int q = 0; q < 2; ++q)
+            if (active[q]) FLIP_CHECK(hipStreamSynchronize(ctx->pair_stream[q]));
+        for (int q = 0; q < 2; ++q)
+            if (active[q] && (done[q] || run[q].launched > run[q].max_iter)) active[q] = false;
+    }
+    PcgTail tail[2];
+    for (int q = 0; q < 2; ++q)
+        if ((rc = with_system(q, [&] { return pcg_enqueue_tail(ctx, tail[q]); }))) return rc;
+    for (int q = 0; q < 2; ++q) {
+        FLIP_CHECK(hipStreamSynchronize(ctx->pair_stream[q]));
+        // later work on the context's own stream is ordered after both solves
+        FLIP_CHECK(hipEventRecord(ctx->pair_event[q], ctx->pair_stream[q]));
+        FLIP_CHECK(hipStreamWaitEvent(main_stream, ctx->pair_event[q], 0));
+    }
+    if ((rc = pcg_report(ctx, run[0], tail[0], info_divergence))) return rc;
+    flip_swap_systems(ctx);
+    rc = pcg_report(ctx, run[1], tail[1], info_density);
+    flip_swap_systems(ctx);
+    return rc;
+}
+
+extern "C" int flip_select_system(flip_ctx *ctx, int kind) {
+    FLIP_REQUIRE(ctx, "null context");
+    if (ctx->sys_kind == kind) return 0;
+    FLIP_REQUIRE(ctx->other.allocated && ctx->other.sys_kind == kind, "flip_select_system: no assembled system of this kind");
+    flip_swap_systems(ctx);
     return 0;
 }
 

@@ -3,7 +3,7 @@
 // the .vdb output.
 //
 //   flip_scene [--n 64] [--frames 3] [--t-frame 0.01] [--ratio 0.95] [--fill PPC | --source RATE]
-//              [--dam] [--sphere] [--no-advect] [--no-constrain] [--no-density] [--jacobi] [--seed S] [--dump DIR] [--quiet]
+//              [--dam] [--sphere] [--no-advect] [--no-constrain] [--no-density] [--jacobi] [--sequential] [--seed S] [--dump DIR] [--quiet]
 //
 // --dump DIR writes the inputs of the first substep and the particle state after the last frame as raw
 // little-endian arrays plus a small text header, for checks against an independent implementation.
@@ -44,7 +44,7 @@ void dumpParticles(const std::string &dir, const char *tag, ParticleSet &ps) {
 int main(int argc, char **argv) {
     int n = 64, frames = 3, fill_ppc = 8, source_rate = 0, device = 0;
     float t_frame = 0.01f, ratio = 0.95f;
-    bool dam = false, sphere = false, constrain = true, advect = true, density_on = true, jacobi = false, quiet = false;
+    bool dam = false, sphere = false, constrain = true, advect = true, density_on = true, jacobi = false, quiet = false, sequential = false;
     uint64_t seed = 12345;
     std::string dump_dir;
     for (int a = 1; a < argc; ++a) {
@@ -62,6 +62,7 @@ int main(int argc, char **argv) {
         else if (is("--no-constrain")) constrain = false;
         else if (is("--no-density")) density_on = false;
         else if (is("--jacobi")) jacobi = true;
+        else if (is("--sequential")) sequential = true;
         else if (is("--quiet")) quiet = true;
         else if (is("--seed")) seed = strtoull(next(), nullptr, 10);
         else if (is("--device")) device = atoi(next());
@@ -90,6 +91,7 @@ int main(int argc, char **argv) {
     sim.advect = advect;
     sim.constrain = constrain;
     sim.density_constraint = density_on;
+    sim.concurrent_solves = !sequential;
     sim.verbose = !quiet;
     if (jacobi) sim.preconditioner = FLIP_PRECOND_JACOBI;
 

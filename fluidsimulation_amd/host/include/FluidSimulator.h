@@ -30,6 +30,8 @@ public:
     int solver_max_iterations = 0;     // <= 0: 2 * rows, the Eigen default
     int preconditioner = FLIP_PRECOND_MULTIGRID;
     bool density_constraint = true;    // DENSITY_CONSTRAINT_PPE
+    bool concurrent_solves = true;     // both systems assembled first and solved side by side (flip_solve_pair): the
+                                       // density system does not depend on the divergence solve; same results
     bool advect = true;                // FluidDomain::advectParticles inside the substep
     bool constrain = true;             // the two constrain_velocity calls of the substep
     bool verbose = true;               // the reference prints per-substep timings
@@ -52,4 +54,5 @@ private:
     void transfer_from_grid_to_particles(FluidDomain &domain, float flip_pic_ratio);
     void apply_particle_displacements(FluidDomain &domain);
     const flipvdb::CoordBBox _bbox;
+    bool _density_already_solved = false;  // this substep's density system was solved together with the divergence one
 };

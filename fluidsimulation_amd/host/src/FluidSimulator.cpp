@@ -159,8 +159,17 @@ FlipSolveReport report(const flip_pcg_info &i) {
 void FluidSimulator::solve_pressure_divirgence(FluidDomain &domain, float dt) {
     FlipDevice &dev = domain.device();
     flip_pcg_info info;
-    dev.check(flip_build_system(dev.ctx(), FLIP_SOLVE_DIVERGENCE, dt), "flip_build_system");
-    dev.check(flip_pcg_solve(dev.ctx(), solver_tolerance, solver_max_iterations, preconditioner, &info), "flip_pcg_solve");
+    _density_already_solved = false;
+    if (density_constraint && concurrent_solves) {
+        flip_pcg_info info_density;
+        dev.check(flip_solve_pair(dev.ctx(), dt, solver_tolerance, solver_max_iterations, preconditioner, &info, &info_density),
+                  "flip_solve_pair");
+        last_density_solve = report(info_density);
+        _density_already_solved = true;
+    } else {
+        dev.check(flip_build_system(dev.ctx(), FLIP_SOLVE_DIVERGENCE, dt), "flip_build_system");
+        dev.check(flip_pcg_solve(dev.ctx(), solver_tolerance, solver_max_iterations, preconditioner, &info), "flip_pcg_solve");
+    }
     last_divergence_solve = report(info);
     dev.check(flip_project_velocity(dev.ctx(), dt), "flip_project_velocity");
     domain.fetchSolidObjectVelocity(); // :1095-1100
@@ -169,6 +178,12 @@ void FluidSimulator::solve_pressure_divirgence(FluidDomain &domain, float dt) {
 // src/FluidSimulator.cpp:510-524 (assembly :832-990, CG :1006-1007, projection :1104-1178)
 void FluidSimulator::solve_pressure_density(FluidDomain &domain, float dt) {
     FlipDevice &dev = domain.device();
+    if (_density_already_solved) {
+        dev.check(flip_select_system(dev.ctx(), FLIP_SOLVE_DENSITY), "flip_select_system");
+        dev.check(flip_project_displacement(dev.ctx(), dt), "flip_project_displacement");
+        dev.check(flip_select_system(dev.ctx(), FLIP_SOLVE_DIVERGENCE), "flip_select_system");
+        return;
+    }
     flip_pcg_info info;
     dev.check(flip_build_system(dev.ctx(), FLIP_SOLVE_DENSITY, dt), "flip_build_system");
     dev.check(flip_pcg_solve(dev.ctx(), solver_tolerance, solver_max_iterations, preconditioner, &info), "flip_pcg_solve");

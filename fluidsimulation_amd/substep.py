@@ -14,8 +14,11 @@ from .binding import FlipContext, PRECOND_JACOBI, SOLVE_DENSITY, SOLVE_DIVERGENC
 class FlipSubstep:
     def __init__(self, ctx: FlipContext, flip_pic_ratio: float = 0.95, tol: float = 1e-15, max_iter: int = 0,
                  precond: int = PRECOND_JACOBI, density_projection: bool = True, constrain: bool = False,
-                 advect: bool = False, rigid_body: bool = False, levelset_radius: float | None = None):
+                 advect: bool = False, rigid_body: bool = False, levelset_radius: float | None = None,
+                 concurrent_solves: bool = False):
         self.ctx = ctx
+        # the density system does not depend on the divergence solve: both can be assembled first and solved side by side
+        self.concurrent_solves = concurrent_solves and density_projection
         self.ratio = flip_pic_ratio      # main.cpp:167
         self.tol = tol                   # src/FluidSimulator.cpp:660
         self.max_iter = max_iter
@@ -45,11 +48,18 @@ class FlipSubstep:
         c.index_cells()                           # :486  (weights of the previous substep)
         c.face_fractions()                        # :488
         c.density(want_count=False)               # :491
-        c.build_system(SOLVE_DIVERGENCE, dt)      # :505
-        info_div = c.pcg_solve(self.tol, self.max_iter, self.precond)
-        c.project_velocity(dt)                    # :507
         info_den = None
-        if self.density_projection:
+        if self.concurrent_solves:
+            info_div, info_den = c.solve_pair(dt, self.tol, self.max_iter, self.precond)   # :505 and :521
+            c.project_velocity(dt)                # :507
+            c.select_system(SOLVE_DENSITY)
+            c.project_displacement(dt)            # :523
+            c.select_system(SOLVE_DIVERGENCE)
+        else:
+            c.build_system(SOLVE_DIVERGENCE, dt)  # :505
+            info_div = c.pcg_solve(self.tol, self.max_iter, self.precond)
+            c.project_velocity(dt)                # :507
+        if self.density_projection and not self.concurrent_solves:
             c.build_system(SOLVE_DENSITY, dt)     # :521
             info_den = c.pcg_solve(self.tol, self.max_iter, self.precond)
             c.project_displacement(dt)            # :523

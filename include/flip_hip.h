@@ -231,6 +231,16 @@ int flip_system_download(flip_ctx *ctx, double *off, double *diag, double *rhs);
  * until |r|^2 < tol^2 |b|^2 or max_iter operator applications (max_iter <= 0: 2*rows, the
  * Eigen default).  Result in FLIP_F_PRESSURE. */
 int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int precond, flip_pcg_info *info);
+/* Both solves of a substep at once (src/FluidSimulator.cpp:505 and :521).  Neither system depends on the other's
+ * solution (the density system reads labels, level sets, face fractions and the density field only), so this call
+ * assembles both, iterates on them side by side on two internal streams and returns when both have stopped; each solve
+ * performs the same operations as flip_build_system + flip_pcg_solve.  A context then holds two assembled systems:
+ * flip_select_system(ctx, kind) makes one of them the active one, which flip_project_velocity (FLIP_SOLVE_DIVERGENCE),
+ * flip_project_displacement (FLIP_SOLVE_DENSITY), FLIP_F_PRESSURE and flip_system_download refer to.  On return the
+ * divergence system is active. */
+int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_iter, int precond, flip_pcg_info *info_divergence,
+                    flip_pcg_info *info_density);
+int flip_select_system(flip_ctx *ctx, int kind);
 /* y = A x for the assembled system on dense box vectors (parity hook for the SpMV kernel). */
 int flip_apply_operator(flip_ctx *ctx, const double *x_host, double *y_host);
 /* When enabled, flip_pcg_solve brackets a sample of its operator launches with HIP events and

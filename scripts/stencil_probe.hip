@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <chrono>
 #define BLK 256
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -218,6 +219,34 @@ int main(int argc, char **argv) {
         run("k3 32-bit ids", k3, A, nblk, bytes);
         run("k4 own cell only", k4, A, nblk, bytes);
         run("k5 x neighbours by shuffle", k5, A, nblk, bytes);
+    }
+    // the production form on two streams at once, each with its own vectors: does a pair of such kernels overlap?
+    {
+        double *z2 = (double *)dalloc((B + 2 * pad) * 8) + pad, *pold2 = (double *)dalloc((B + 2 * pad) * 8) + pad;
+        double *pnew2 = (double *)dalloc((B + 2 * pad) * 8) + pad, *ap2 = (double *)dalloc((B + 2 * pad) * 8) + pad;
+        double *partial2 = (double *)dalloc(4096 * 8);
+        CK(hipMemcpy(z2, hz.data(), B * 8, hipMemcpyHostToDevice));
+        Args A2 = A;
+        A2.z = z2; A2.pold = pold2; A2.pnew = pnew2; A2.ap = ap2; A2.partial = partial2;
+        hipStream_t s[2];
+        for (int q = 0; q < 2; ++q) CK(hipStreamCreateWithFlags(&s[q], hipStreamNonBlocking));
+        for (int nblk : { 512, 1024 }) {
+            A.nblk = A2.nblk = nblk;
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            const int reps = 200;
+            for (int two = 0; two < 2; ++two) {
+                CK(hipDeviceSynchronize());
+                auto t0 = std::chrono::steady_clock::now();
+                for (int r = 0; r < reps; ++r) {
+                    k0<<<nblk, BLK, 0, s[0]>>>(A);
+                    if (two) k0<<<nblk, BLK, 0, s[1]>>>(A2);
+                }
+                CK(hipDeviceSynchronize());
+                const double us = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6 / reps;
+                printf("k0 nblk %d on %s: %.2f us per launch%s\n", nblk, two ? "two streams" : "one stream", us, two ? " pair" : "");
+            }
+        }
     }
     return 0;
 }
