@@ -6,25 +6,51 @@
 // Binning.  cell(p) = floor(pos + 0.5) per axis (OpenVDB Coord::round of the index position).
 // Outside particles go to the extra bin B.
 
+// The particles arrive in the order of the previous sort and move less than a cell per substep, so neighbouring lanes
+// mostly hold the same cell: a run of equal cells within a wave issues one atomic for the whole run instead of one per
+// particle (same-address atomics serialise).  Returns the run's first lane and its length to every lane of the run.
+__device__ __forceinline__ void d_wave_run(int32_t c, int &start, int &len) {
+    const int lane = threadIdx.x & (FLIP_WAVE - 1);
+    const int32_t prev = __shfl_up(c, 1, FLIP_WAVE);
+    const bool head = lane == 0 || prev != c;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull); // bits 0..lane
+    start = 63 - __clzll((long long)(heads & upto));
+    const unsigned long long above = heads & ~upto;
+    const int end = above ? __ffsll((long long)above) - 1 : FLIP_WAVE;
+    len = end - start;
+}
+
 __global__ void k_cell_ids(GridDims g, long long n, const double *__restrict__ x, const double *__restrict__ y,
                            const double *__restrict__ z, int32_t *__restrict__ cell_id, int32_t *__restrict__ counts) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    const int i = (int)floor(x[s] + 0.5) - g.ox;
-    const int j = (int)floor(y[s] + 0.5) - g.oy;
-    const int k = (int)floor(z[s] + 0.5) - g.oz;
-    const int32_t c = d_inside(g, i, j, k) ? (int32_t)d_lid(g, i, j, k) : (int32_t)g.B;
-    cell_id[s] = c;
-    atomicAdd(&counts[c], 1); // integer: the result does not depend on the order of arrival
+    int32_t c = -1;
+    if (s < n) {
+        const int i = (int)floor(x[s] + 0.5) - g.ox;
+        const int j = (int)floor(y[s] + 0.5) - g.oy;
+        const int k = (int)floor(z[s] + 0.5) - g.oz;
+        c = d_inside(g, i, j, k) ? (int32_t)d_lid(g, i, j, k) : (int32_t)g.B;
+        cell_id[s] = c;
+    }
+    int start, len;
+    d_wave_run(c, start, len);
+    // integer: the result does not depend on the order of arrival
+    if (c >= 0 && (int)(threadIdx.x & (FLIP_WAVE - 1)) == start) atomicAdd(&counts[c], len);
 }
 
 __global__ void k_scatter_slots(long long n, const int32_t *__restrict__ cell_id, const int32_t *__restrict__ pid,
                                 const int32_t *__restrict__ cell_start, int32_t *__restrict__ fill,
                                 int32_t *__restrict__ slot_src, int32_t *__restrict__ slot_key) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    const int32_t c = cell_id[s];
-    const int32_t slot = cell_start[c] + atomicAdd(&fill[c], 1);
+    const int32_t c = s < n ? cell_id[s] : -1;
+    int start, len;
+    d_wave_run(c, start, len);
+    const int lane = threadIdx.x & (FLIP_WAVE - 1);
+    int32_t base = 0;
+    if (c >= 0 && lane == start) base = cell_start[c] + atomicAdd(&fill[c], len);
+    base = __shfl(base, start, FLIP_WAVE);
+    if (c < 0) return;
+    const int32_t slot = base + (lane - start);
     slot_src[slot] = (int32_t)s;
     slot_key[slot] = pid[s];
 }
