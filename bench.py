@@ -125,7 +125,8 @@ def cpu_baseline(sc, args, jacobi_iters):
     return {"value": 1.0 / total, "unit": "substeps/s", "cores": threads, "kind": "port",
             "sample": f"all non-solver stages once at full size ({fixed:.2f} s) + {args.cpu_iters} Jacobi-CG iterations per "
                       f"solve ({t_iter[0] * 1e3:.1f}/{t_iter[1] * 1e3:.1f} ms per iteration), extrapolated to the "
-                      f"{jacobi_iters[0]}+{jacobi_iters[1]} iterations Jacobi CG needs on this scene (counted on the GPU)",
+                      f"{jacobi_iters[0]}+{jacobi_iters[1]} iterations Jacobi CG needs on this scene (counted on the GPU); particle state "
+                      f"as after the timed steps",
             "stage_seconds": {k: round(v, 4) for k, v in t.items()}}
 
 
@@ -135,7 +136,7 @@ def stored_traffic(kernel_prefix):
     for streaming reads) + WRITE_SIZE, both reported in KB.  None when the files are absent."""
     import csv
     vals = {}
-    for key, name in (("fetch", "r01_c_bench256_mg_pmc_fetch_size.csv"), ("write", "r01_c_bench256_mg_pmc_write_size.csv")):
+    for key, name in (("fetch", "r01_d_bench256_mg_pmc_fetch_size.csv"), ("write", "r01_d_bench256_mg_pmc_write_size.csv")):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             return None
@@ -310,7 +311,7 @@ def main():
                     "converged": all(s["converged"] == 1 for s in solves)},
             "roofline": {"bound": "hbm", "kernel": "k_pcg_direction", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
-                         "traffic_source": "profiles/r01_c_bench256_mg_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc "
+                         "traffic_source": "profiles/r01_d_bench256_mg_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc "
                                            "passes of this command; 2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)" if traffic else None,
                          "algorithmic_bytes_per_launch": rows * DIRECTION_BYTES_PER_ROW,
                          "bytes_per_row": DIRECTION_BYTES_PER_ROW, "rows_per_launch": rows,
@@ -318,6 +319,9 @@ def main():
             "roofline_other_kernels": kernels,
         }
         if jacobi_iters is not None:
+            # the CPU works on the state the device has reached, not on the fluid at rest: from rest the vectors of the
+            # first solve are full of denormals, which the reference's build (no flush-to-zero) crawls through
+            sc.pos, sc.vel = ctx.download_particles()
             out["cpu_baseline"] = cpu_baseline(sc, args, jacobi_iters)
         print(json.dumps(out))
     ctx.close()

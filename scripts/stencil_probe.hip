@@ -171,6 +171,48 @@ __global__ void __launch_bounds__(BLK) k5(Args A) {
     EPILOGUE
 }
 
+// K6: k4's work as a one-shot grid (one row per thread, no loop, no reduction): cost of the persistent form
+__global__ void __launch_bounds__(BLK) k6(Args A) {
+    const long long q = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (q >= A.n) return;
+    const long long c = A.rows[q];
+    const double pc = A.z[c] + A.beta * A.pold[c];
+    const double s = A.diag[c] * pc - A.s2 * ((double)A.cx[c] + (double)A.cy[c] + (double)A.cz[c]);
+    A.pnew[c] = pc;
+    A.ap[c] = s;
+}
+// K7: the production stencil as a one-shot grid, without the reduction
+__global__ void __launch_bounds__(BLK) k7(Args A) {
+    const long long q = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (q >= A.n) return;
+    const double *__restrict__ z = A.z, *__restrict__ pold = A.pold, *__restrict__ dg = A.diag;
+    const float *__restrict__ cx = A.cx, *__restrict__ cy = A.cy, *__restrict__ cz = A.cz;
+    const long long sy = A.sy, sz = A.sz;
+    const double beta = A.beta;
+    double pap = 0.0;
+    const long long c = A.rows[q];
+    BODY(c)
+    (void)pap;
+}
+// K8: one-shot, two rows per thread
+__global__ void __launch_bounds__(BLK) k8(Args A) {
+    const long long q0 = ((long long)blockIdx.x * BLK) * 2 + threadIdx.x;
+    const double *__restrict__ z = A.z, *__restrict__ pold = A.pold, *__restrict__ dg = A.diag;
+    const float *__restrict__ cx = A.cx, *__restrict__ cy = A.cy, *__restrict__ cz = A.cz;
+    const long long sy = A.sy, sz = A.sz;
+    const double beta = A.beta;
+    double pap = 0.0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const long long q = q0 + u * BLK;
+        if (q < A.n) {
+            const long long c = A.rows[q];
+            BODY(c)
+        }
+    }
+    (void)pap;
+}
+
 template <class K>
 static void run(const char *name, K kern, Args A, int nblk, double bytes) {
     hipEvent_t e0, e1;
@@ -219,6 +261,12 @@ int main(int argc, char **argv) {
         run("k3 32-bit ids", k3, A, nblk, bytes);
         run("k4 own cell only", k4, A, nblk, bytes);
         run("k5 x neighbours by shuffle", k5, A, nblk, bytes);
+    }
+    {
+        const int g1 = (int)((n + BLK - 1) / BLK);
+        run("k6 own cell, one-shot grid", k6, A, g1, bytes);
+        run("k7 stencil, one-shot grid", k7, A, g1, bytes);
+        run("k8 stencil, one-shot x2", k8, A, (g1 + 1) / 2, bytes);
     }
     // the production form on two streams at once, each with its own vectors: does a pair of such kernels overlap?
     {
