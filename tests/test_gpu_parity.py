@@ -544,3 +544,35 @@ def test_solving_both_systems_side_by_side_changes_nothing(precond):
     assert np.array_equal(pna, pnb)          # density pressure of the last substep
     # sequentially the divergence pressure has been overwritten by the density solve; paired both are kept
     assert pda is None and np.abs(pdb).max() > 0
+
+
+@pytest.mark.gpu
+def test_side_by_side_solves_with_a_rigid_body_and_with_no_fluid():
+    """The coupled divergence system takes the plain-launch path of flip_solve_pair (its kernels carry per-solve
+    arguments); an empty scene has no rows in either system."""
+    sc = scenes.cube_drop(24, ppc=4, seed=9)
+    scenes.add_sphere(sc, radius_world=0.12, centre_world=(0.5, 0.3, 0.5), density=500.0, vel=(0.05, -0.3, 0.02, 0.4, 0.0, -0.2))
+    dx = float(sc.dx)
+    keep = np.linalg.norm((sc.pos + 0.5) * dx - np.array([0.5, 0.3, 0.5]), axis=1) > 0.12 + 0.5 * dx
+    sc.pos, sc.vel, sc.mass = sc.pos[keep].copy(), sc.vel[keep].copy(), sc.mass[keep].copy()
+    sc.phi_fluid = scenes.fluid_levelset(sc, sc.pos)
+    sc.vel = np.random.default_rng(2).normal(0, 0.1, sc.pos.shape)
+    from fluidsimulation_amd import FlipSubstep
+    got = []
+    for paired in (False, True):
+        with FlipContext(sc.desc()) as ctx:
+            ctx.upload_scene(sc)
+            st = FlipSubstep(ctx, precond=0, max_iter=20000, rigid_body=True, constrain=True, concurrent_solves=paired)
+            infos = [st.step(0.004) for _ in range(2)]
+            got.append((infos, ctx.download_particles(), ctx.solid_object_velocity()))
+    for k in ("divergence", "density"):
+        assert got[0][0][1][k]["iterations"] == got[1][0][1][k]["iterations"] and got[1][0][1][k]["converged"] == 1
+    assert np.array_equal(got[0][1][0], got[1][1][0]) and np.array_equal(got[0][1][1], got[1][1][1])
+    assert np.array_equal(got[0][2], got[1][2])
+    empty = scenes.container(12)
+    with FlipContext(empty.desc()) as ctx:
+        ctx.upload("phi_solid", empty.phi_solid)
+        ctx.upload_particles(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0, np.float32))
+        info = FlipSubstep(ctx, precond=1, concurrent_solves=True).step(0.004)
+        for k in ("divergence", "density"):
+            assert info[k]["rows"] == 0 and info[k]["iterations"] == 0
