@@ -60,7 +60,7 @@ int flip_alloc_system(flip_ctx *c) {
     for (int a = 0; a < 3; ++a) A(c->term[a], B)
     A(c->flags, B) A(c->diag, B) A(c->invdiag, B) A(c->rhs, B)
     {
-        double **dp[] = { &c->x, &c->r, &c->z, &c->pv[0], &c->pv[1], &c->ap, &c->cg_diag, &c->cg_inv };
+        double **dp[] = { &c->x, &c->r, &c->r2, &c->z, &c->pv[0], &c->pv[1], &c->ap, &c->cg_diag, &c->cg_inv };
         for (double **q : dp) {
             A(*q, B + 2 * c->pad)
             if (e == hipSuccess) *q += c->pad;
@@ -83,7 +83,7 @@ void flip_free_system(flip_ctx *c) {
     for (int a = 0; a < 3; ++a) dfree(c->term[a]);
     dfree(c->flags); dfree(c->diag); dfree(c->invdiag); dfree(c->rhs);
     {   // padded solver arrays: the stored pointers are offset by c->pad
-        double **dp[] = { &c->x, &c->r, &c->z, &c->pv[0], &c->pv[1], &c->ap, &c->cg_diag, &c->cg_inv };
+        double **dp[] = { &c->x, &c->r, &c->r2, &c->z, &c->pv[0], &c->pv[1], &c->ap, &c->cg_diag, &c->cg_inv };
         for (double **q : dp)
             if (*q) { (void)hipFree(*q - c->pad); *q = nullptr; }
         for (int a = 0; a < 3; ++a)
@@ -102,7 +102,7 @@ void flip_swap_systems(flip_ctx *c) {
     std::swap(c->sys_coupled, o.sys_coupled); std::swap(c->sys_eliminated, o.sys_eliminated);
     for (int a = 0; a < 3; ++a) { std::swap(c->term[a], o.term[a]); std::swap(c->cg_c[a], o.cg_c[a]); }
     std::swap(c->flags, o.flags); std::swap(c->diag, o.diag); std::swap(c->invdiag, o.invdiag); std::swap(c->rhs, o.rhs);
-    std::swap(c->x, o.x); std::swap(c->r, o.r); std::swap(c->z, o.z); std::swap(c->pv[0], o.pv[0]); std::swap(c->pv[1], o.pv[1]);
+    std::swap(c->x, o.x); std::swap(c->r, o.r); std::swap(c->r2, o.r2); std::swap(c->z, o.z); std::swap(c->pv[0], o.pv[0]); std::swap(c->pv[1], o.pv[1]);
     std::swap(c->ap, o.ap); std::swap(c->cg_diag, o.cg_diag); std::swap(c->cg_inv, o.cg_inv);
     std::swap(c->cg_rows, o.cg_rows); std::swap(c->chunk_flag, o.chunk_flag); std::swap(c->chunk_list, o.chunk_list);
     std::swap(c->d_counts, o.d_counts); std::swap(c->n_active_chunks, o.n_active_chunks);

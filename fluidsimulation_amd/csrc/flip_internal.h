@@ -33,6 +33,8 @@ struct flip_pcg_scalars {
     int32_t it_b;        // iteration the next update kernel runs
     int32_t done;        // set once converged (or |b| = 0)
     int32_t max_iter;
+    int32_t fused;       // the update kernel also pre-smooths (k_pcg_update_pre): the residual alternates between two
+                         // buffers, the current one being number it_a & 1
 };
 
 // Packed particle record read by the gather kernels (P2G, density): one 64-byte line per particle instead of
@@ -76,7 +78,7 @@ struct flip_system_set {
     float *term[3] = {};
     uint8_t *flags = nullptr;
     double *diag = nullptr, *invdiag = nullptr, *rhs = nullptr;
-    double *x = nullptr, *r = nullptr, *z = nullptr, *pv[2] = {}, *ap = nullptr;
+    double *x = nullptr, *r = nullptr, *r2 = nullptr, *z = nullptr, *pv[2] = {}, *ap = nullptr;
     float *cg_c[3] = {};
     double *cg_diag = nullptr, *cg_inv = nullptr;
     int32_t *cg_rows = nullptr, *chunk_flag = nullptr, *chunk_list = nullptr, *d_counts = nullptr;
@@ -152,6 +154,7 @@ struct flip_ctx {
     // kernels read c +- 1, c +- nx, c +- nx*ny of any cell of the box without a bounds test.
     int64_t pad = 0;
     double *x = nullptr, *r = nullptr, *z = nullptr, *pv[2] = {}, *ap = nullptr;
+    double *r2 = nullptr;           // second residual buffer of the fused update + pre-smoothing kernel
     // CG view of the system: symmetric coupling coefficient toward the low x/y/z neighbour (0 = none),
     // diagonal and Jacobi inverse; all zero on cells that are not rows of the CG system
     float *cg_c[3] = {};
@@ -201,8 +204,10 @@ int flip_alloc_system(flip_ctx *ctx);      // the active system's arrays (used f
 void flip_free_system(flip_ctx *ctx);
 void flip_swap_systems(flip_ctx *ctx);     // active <-> other
 int flip_mg_setup(flip_ctx *ctx);   // coarse operators of the assembled system
-int flip_mg_vcycle(flip_ctx *ctx);  // z = M^-1 r and the r.z partials
+int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed = false);  // z = M^-1 r and the r.z partials; pre_smoothed: level 0's
+                                                               // pre-smoothing has been done by k_pcg_update_pre
 void flip_mg_free(flip_ctx *ctx);
+void flip_mg_smoother(double *c1, double *a2, double *c2); // coefficients of the level smoother (see flip_mg.hip)
 
 int flip_fail(flip_ctx *ctx, const char *what, const char *file, int line);
 int flip_fail_hip(flip_ctx *ctx, hipError_t e, const char *what, const char *file, int line);

@@ -40,6 +40,7 @@ static MgCheb mg_cheb() {
     }();
     return k;
 }
+void flip_mg_smoother(double *c1, double *a2, double *c2) { const MgCheb k = mg_cheb(); *c1 = k.c1; *a2 = k.a2; *c2 = k.c2; }
 #define MG_COARSEST_CELLS 4096   // one workgroup of 1024 threads, at most 4 cells per thread
 #define MG_COARSEST_LDS (60 * 1024) // its two padded vectors must fit the default dynamic LDS limit
 #define MG_COARSEST_SWEEPS 12          // 24 gave the same CG iteration count at 256^3 (61.8 against 61.0 per substep), 8 costs 3 more
@@ -55,9 +56,18 @@ struct MgDev {
     const CT *diag, *inv;     // diagonal and its inverse (0 off the rows); level 0 reads float copies: the
                               // preconditioner does not need the last bits and these are a sixth of its traffic
     double *x, *b, *t;
+    const double *b_alt;             // level 0 only: the second residual buffer of the fused update kernel
+    const flip_pcg_scalars *S;       // level 0 only: says which of b / b_alt is current (nullptr: always b)
     const int32_t *rows;
     const int32_t *n_rows;
 };
+
+// The right-hand side of a level: on level 0 the CG residual, which alternates between two buffers when the update
+// kernel is the fused one (the buffer written by update number it_a - 1 is number it_a & 1).
+template <class CT>
+__device__ __forceinline__ const double *d_mg_rhs(const MgDev<CT> &L) {
+    return (L.S && L.S->fused && (L.S->it_a & 1)) ? L.b_alt : L.b;
+}
 
 template <class CT>
 __device__ __forceinline__ double d_mg_apply(const MgDev<CT> &L, long long c, const double *__restrict__ v) {
@@ -77,7 +87,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_pre(MgDev<CT> L, const int32_
     if (done && *done) return;
     const long long n = *L.n_rows;
     const CT *__restrict__ inv = L.inv;
-    const double *__restrict__ b = L.b;
+    const double *__restrict__ b = d_mg_rhs(L);
 #pragma unroll 2
     for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
         const long long c = L.rows[q];
@@ -114,6 +124,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, MgDev<dou
     __shared__ double scratch[4];
     if (done && *done) return;
     const long long n = *L.n_rows;
+    const double *__restrict__ rhs = d_mg_rhs(L);
     double acc = 0.0;
     if (RZ) {
         // same split of the row list as the CG kernels, so the partial layout matches their reduction
@@ -123,7 +134,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, MgDev<dou
 #pragma unroll 2
         for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
             const long long c = L.rows[q];
-            const double b = L.b[c];
+            const double b = rhs[c];
             const double v = d_mg_second_step(L, C, c, in, out, b);
             out[c] = v;
             acc += b * v;
@@ -134,7 +145,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, MgDev<dou
 #pragma unroll 2
         for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
             const long long c = L.rows[q];
-            out[c] = d_mg_second_step(L, C, c, in, out, L.b[c]);
+            out[c] = d_mg_second_step(L, C, c, in, out, rhs[c]);
         }
     }
 }
@@ -147,6 +158,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post(MgDev<CT> F, MgDev<doubl
     if (done && *done) return;
     const long long n = *F.n_rows;
     const double *__restrict__ xc = C.x;
+    const double *__restrict__ rhs = d_mg_rhs(F);
 #pragma unroll 2
     for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
         const long long c = F.rows[q];
@@ -168,7 +180,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post(MgDev<CT> F, MgDev<doubl
         acc += (double)F.cz[c] * (in[c - sz] + xc[pzm]);
         acc += (double)F.cz[c + sz] * (in[c + sz] + xc[pzp]);
         const double Av = (double)F.diag[c] * v0 - F.scale * acc;
-        out[c] = v0 + F.c1 * (double)F.inv[c] * (F.b[c] - Av);
+        out[c] = v0 + F.c1 * (double)F.inv[c] * (rhs[c] - Av);
     }
 }
 
@@ -179,6 +191,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<d
                                                            const double *__restrict__ v) {
     if (done && *done) return;
     const long long n = *C.n_rows;
+    const double *__restrict__ rhs = d_mg_rhs(F);
     const int child = threadIdx.x & 7;
     const int di = child & 1, dj = (child >> 1) & 1, dk = child >> 2;
     for (long long q = ((long long)blockIdx.x * FLIP_BLOCK + threadIdx.x) >> 3; q < ((n + 31) & ~31LL);
@@ -193,7 +206,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<d
             const int i = 2 * I + di, j = 2 * J + dj, k = 2 * K + dk;
             if (i < F.nx && j < F.ny && k < F.nz) {
                 const long long c = (long long)i + F.sy * j + F.sz * k;
-                if (F.inv[c] != (CT)0) s = F.b[c] - d_mg_apply(F, c, v);
+                if (F.inv[c] != (CT)0) s = rhs[c] - d_mg_apply(F, c, v);
             }
         }
         s += __shfl_xor(s, 1, FLIP_WAVE);
@@ -406,7 +419,8 @@ static MgDev<float> mg_level0(flip_ctx *ctx) {
     L.scale = ctx->sys_s2;
     { const MgCheb k = mg_cheb(); L.c1 = k.c1; L.a2 = k.a2; L.c2 = k.c2; }
     L.diag = ctx->mg_diag_f; L.inv = ctx->mg_inv_f;
-    L.x = ctx->z; L.b = (wide && ctx->slab_weighted) ? ctx->dist_rw : ctx->r; L.t = ctx->ap;   // z = M^-1 r; Ap is free between the update and direction kernels
+    L.x = ctx->z; L.b = (wide && ctx->slab_weighted) ? ctx->dist_rw : ctx->r; L.t = ctx->ap;
+    L.b_alt = ctx->r2; L.S = ctx->scal;   // z = M^-1 r; Ap is free between the update and direction kernels
     L.rows = wide ? ctx->mg_rows : ctx->cg_rows; L.n_rows = ctx->d_counts + (wide ? 7 : 6);
     return L;
 }
@@ -419,6 +433,7 @@ static MgDev<double> mg_level(const flip_mg_level &S) {
     { const MgCheb k = mg_cheb(); L.c1 = k.c1; L.a2 = k.a2; L.c2 = k.c2; }
     L.diag = S.diag; L.inv = S.inv;
     L.x = S.x; L.b = S.b; L.t = S.t;
+    L.b_alt = nullptr; L.S = nullptr;
     L.rows = S.rows; L.n_rows = S.n_rows;
     return L;
 }
@@ -474,14 +489,14 @@ static int mg_blocks(const flip_ctx *ctx, int64_t B) {
 }
 
 // One V-cycle: z = M^-1 r on level 0, and the partials of r.z in slot 1 for the next direction kernel.
-int flip_mg_vcycle(flip_ctx *ctx) {
+int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed) {
     hipStream_t st = ctx->stream;
     const int32_t *done = &ctx->scal->done;
     const int nblk = ctx->pcg_blocks;
     const size_t nl = ctx->mg.size();
     MgDev<float> L0 = mg_level0(ctx);
     // ---- down: pre-smooth (result in x), restrict the residual ----
-    k_mg_pre<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.x);
+    if (!pre_smoothed) k_mg_pre<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.x);
     k_mg_restrict<float><<<mg_blocks(ctx, ctx->mg[0].B * 8), FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x);
     for (size_t l = 0; l + 1 < nl; ++l) {
         MgDev<double> F = mg_level(ctx->mg[l]);

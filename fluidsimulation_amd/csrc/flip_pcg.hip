@@ -640,6 +640,60 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update(PcgArgs A) {
     }
 }
 
+// k_pcg_update and the pre-smoothing of the V-cycle's level 0 (k_mg_pre in flip_mg.hip) in one pass: the smoother
+// needs the new residual at the 7 stencil points, which is r - alpha Ap there, so the residual is read from one
+// buffer and written to the other (a neighbour's old value must survive this kernel).  Same operations in the same
+// order as the two kernels, hence the same bits; one launch and one sweep over r less per iteration.
+struct FusedArgs {
+    const float *inv_f, *diag_f;  // float copies of the CG diagonal and its inverse (the V-cycle's level-0 view)
+    double c1, a2, c2;            // smoother coefficients
+    double *r2;
+};
+__global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update_pre(PcgArgs A, FusedArgs F) {
+    __shared__ double scratch[4];
+    flip_pcg_scalars *S = A.scal;
+    if (S->done) return;
+    const int it = S->it_b;
+    const double pap = d_reduce_partials(A.partial + 2 * FLIP_MAX_PCG_BLOCKS, A.nblk, scratch);
+    const double alpha = S->rz[it & 1] / pap;
+    const double *__restrict__ p = (it & 1) ? A.p1 : A.p0;
+    const double *__restrict__ ro = (it & 1) ? F.r2 : A.r;
+    double *__restrict__ rn = (it & 1) ? A.r : F.r2;
+    const double *__restrict__ ap = A.ap;
+    const float *__restrict__ inv = F.inv_f;
+    const float *__restrict__ cx = A.cgx, *__restrict__ cy = A.cgy, *__restrict__ cz = A.cgz;
+    const long long sy = A.sy, sz = A.sz;
+    long long lo, hi;
+    d_row_range(A, lo, hi);
+    double rr = 0.0;
+#pragma unroll 2
+    for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
+        const long long c = A.rows[q];
+        const double rc = ro[c] - alpha * ap[c];
+        const double rxm = ro[c - 1] - alpha * ap[c - 1], rxp = ro[c + 1] - alpha * ap[c + 1];
+        const double rym = ro[c - sy] - alpha * ap[c - sy], ryp = ro[c + sy] - alpha * ap[c + sy];
+        const double rzm = ro[c - sz] - alpha * ap[c - sz], rzp = ro[c + sz] - alpha * ap[c + sz];
+        const double ic = (double)inv[c];
+        const double t0 = F.c1 * ic * rc;
+        double acc = (double)cx[c] * (F.c1 * (double)inv[c - 1] * rxm);
+        acc += (double)cx[c + 1] * (F.c1 * (double)inv[c + 1] * rxp);
+        acc += (double)cy[c] * (F.c1 * (double)inv[c - sy] * rym);
+        acc += (double)cy[c + sy] * (F.c1 * (double)inv[c + sy] * ryp);
+        acc += (double)cz[c] * (F.c1 * (double)inv[c - sz] * rzm);
+        acc += (double)cz[c + sz] * (F.c1 * (double)inv[c + sz] * rzp);
+        const double At = (double)F.diag_f[c] * t0 - A.s2 * acc;
+        A.z[c] = t0 + F.a2 * t0 + F.c2 * ic * (rc - At);
+        A.x[c] = A.x[c] + alpha * p[c];
+        rn[c] = rc;
+        rr += rc * rc;
+    }
+    rr = d_block_sum(rr, scratch);
+    if (threadIdx.x == 0) {
+        A.partial[0 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rr;
+        if (blockIdx.x == 0) S->it_a = it + 1;
+    }
+}
+
 // Back-substitution of the dependent rows: diag x_c = b_c - sum_f A(c,n_f) x_n, x_c = 0 for an all-zero row.
 __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_dependent(PcgArgs A) {
     int lo, hi;
@@ -692,7 +746,7 @@ static int pair_streams(flip_ctx *ctx) {
 }
 
 struct PcgRun {
-    bool use_mg = false, sym = false;
+    bool use_mg = false, sym = false, fused = false;
     int n_prof = 0, launched = 0, max_iter = 0;
 };
 
@@ -710,11 +764,6 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
     hipStream_t st = ctx->stream;
     if (max_iter <= 0) max_iter = 2 * (ctx->n_rows > 0 ? ctx->n_rows : 1);
 
-    flip_pcg_scalars h;
-    memset(&h, 0, sizeof h);
-    h.tol2 = tol * tol;
-    h.max_iter = max_iter;
-    FLIP_CHECK(hipMemcpyAsync(ctx->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
     // cells off the CG rows must read as zero in x and in the vectors the stencil reads at neighbours
     FLIP_CHECK(hipMemsetAsync(ctx->x, 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->z, 0, (size_t)ctx->B * 8, st));
@@ -725,6 +774,14 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
         if (int rc = flip_mg_setup(ctx)) return rc;
         if (ctx->mg.empty()) use_mg = false;
     }
+    static const bool fuse_on = [] { const char *e = getenv("FLIP_FUSED_UPDATE"); return !(e && atoi(e) == 0); }();
+    const bool fused = fuse_on && use_mg && ctx->sys_eliminated && !ctx->sys_coupled;
+    flip_pcg_scalars h;
+    memset(&h, 0, sizeof h);
+    h.tol2 = tol * tol;
+    h.max_iter = max_iter;
+    h.fused = fused ? 1 : 0;
+    FLIP_CHECK(hipMemcpyAsync(ctx->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
     PcgArgs A;
     fill_pcg_args(ctx, A);
     while (ctx->events.size() < 2 + 2 * 64) {
@@ -738,6 +795,7 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
     if (use_mg)
         if (int rc = flip_mg_vcycle(ctx)) return rc;
     run.use_mg = use_mg;
+    run.fused = fused;
     run.sym = ctx->sys_eliminated; // dependent rows eliminated -> symmetric CG system
     run.n_prof = 0;
     run.launched = 0;
@@ -768,7 +826,7 @@ static int pcg_batch(flip_ctx *ctx, PcgRun &run, int batch, bool as_graph) {
         for (size_t q = 0; q < n; ++q) { key ^= b[q]; key *= 1099511628211ull; }
     };
     mix(&A, sizeof A);
-    const int extra[4] = { batch, run.use_mg ? 1 : 0, run.sym ? 1 : 0, (int)ctx->mg.size() };
+    const int extra[5] = { batch, run.use_mg ? 1 : 0, run.sym ? 1 : 0, (int)ctx->mg.size(), run.fused ? 1 : 0 };
     mix(extra, sizeof extra);
     mix(&ctx->mg_diag_f, sizeof ctx->mg_diag_f);
     if (!ctx->batch_exec || ctx->batch_key != key) {
@@ -801,9 +859,17 @@ static int pcg_batch_direct(flip_ctx *ctx, PcgRun &run, int batch, bool allow_ev
         if (run.sym) k_pcg_direction<true><<<nblk, FLIP_BLOCK, 0, st>>>(A);
         else k_pcg_direction<false><<<nblk, FLIP_BLOCK, 0, st>>>(A);
         if (prof) { FLIP_CHECK(hipEventRecord(ctx->events[3 + 2 * run.n_prof], st)); ++run.n_prof; }
-        k_pcg_update<<<nblk, FLIP_BLOCK, 0, st>>>(A);
-        if (run.use_mg)
-            if (int rc = flip_mg_vcycle(ctx)) return rc;
+        if (run.fused) {
+            FusedArgs F;
+            F.inv_f = ctx->mg_inv_f; F.diag_f = ctx->mg_diag_f; F.r2 = ctx->r2;
+            flip_mg_smoother(&F.c1, &F.a2, &F.c2);
+            k_pcg_update_pre<<<nblk, FLIP_BLOCK, 0, st>>>(A, F);
+            if (int rc = flip_mg_vcycle(ctx, true)) return rc;
+        } else {
+            k_pcg_update<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+            if (run.use_mg)
+                if (int rc = flip_mg_vcycle(ctx)) return rc;
+        }
     }
     FLIP_LAUNCH_CHECK();
     run.launched += batch;
