@@ -576,3 +576,31 @@ def test_side_by_side_solves_with_a_rigid_body_and_with_no_fluid():
         info = FlipSubstep(ctx, precond=1, concurrent_solves=True).step(0.004)
         for k in ("divergence", "density"):
             assert info[k]["rows"] == 0 and info[k]["iterations"] == 0
+
+
+@pytest.mark.gpu
+def test_p2g_on_a_wide_box_with_a_crowded_line_is_bit_exact():
+    """A box more than a wave wide (64 cells) with a line of cells holding 40 particles each: velocities, activity
+    and density equal the oracle's bit for bit."""
+    sc = scenes.dam_break(112, ppc=3, seed=4)
+    assert sc.dims[0] >= 64
+    rng = np.random.default_rng(17)
+    # a crowded patch: 40 extra particles per cell in a few cells of one x-line
+    lo = np.array(sc.origin) + np.array(sc.dims) // 2
+    extra = np.concatenate([lo + np.array([dxc, 0, 0]) + rng.uniform(-0.49, 0.49, (40, 3)) for dxc in range(-12, 12)])
+    sc.pos = np.concatenate([sc.pos, extra])
+    sc.vel = rng.normal(0.0, 0.4, sc.pos.shape)
+    sc.mass = np.concatenate([sc.mass, np.full(extra.shape[0], sc.mass[0], np.float32)])
+    o = Oracle(sc.desc())
+    _, cell_start, perm, _ = o.bin_particles(sc.pos)
+    pm2 = o.particle_mask(cell_start, 2)
+    want = o.p2g(sc.pos, sc.vel, cell_start, perm, pm2)
+    dens, _ = o.density(sc.pos, sc.mass, cell_start, perm, pm2, sc.phi_fluid)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        ctx.bin_particles()
+        ctx.p2g()
+        for name, ref in zip(("vel_u", "vel_v", "vel_w"), want):
+            assert np.array_equal(ctx.download(name), ref), name
+        assert np.array_equal(ctx.download("active").astype(bool), pm2.astype(bool))
+        assert np.array_equal(ctx.download("density"), dens)
