@@ -100,11 +100,14 @@ def cpu_baseline(sc, args, jacobi_iters):
     t["density"] = time.perf_counter() - t0
     t_iter = []
     p = None
+    reference_solver = None
     for kind in (0, 1):
         t0 = time.perf_counter()
         off, diag, rhs = o.build_system(kind, dt, label, sc.phi_fluid, sc.phi_solid, w, uvw=uvw, density=dens)
         rowptr, col, val, b = o.to_csr(index, off, diag, rhs)
         t[f"build{kind}"] = time.perf_counter() - t0
+        if kind == 0:
+            reference_solver = reference_pcgsolver(rowptr, col, val, b, sc.phi_fluid[label == 1] >= 0)
         o.cg_jacobi(rowptr, col, val, b, tol=args.tol, max_iter=2)   # thread-pool and page warm-up, not timed
         t0 = time.perf_counter()
         p, it, _ = o.cg_jacobi(rowptr, col, val, b, tol=args.tol, max_iter=args.cpu_iters)
@@ -122,12 +125,40 @@ def cpu_baseline(sc, args, jacobi_iters):
     t["g2p"] = time.perf_counter() - t0
     fixed = sum(t.values())
     total = fixed + t_iter[0] * jacobi_iters[0] + t_iter[1] * jacobi_iters[1]
-    return {"value": 1.0 / total, "unit": "substeps/s", "cores": threads, "kind": "port",
+    return {"value": 1.0 / total, "unit": "substeps/s", "cores": threads, "kind": "port", "reference_solver": reference_solver,
             "sample": f"all non-solver stages once at full size ({fixed:.2f} s) + {args.cpu_iters} Jacobi-CG iterations per "
                       f"solve ({t_iter[0] * 1e3:.1f}/{t_iter[1] * 1e3:.1f} ms per iteration), extrapolated to the "
                       f"{jacobi_iters[0]}+{jacobi_iters[1]} iterations Jacobi CG needs on this scene (counted on the GPU); particle state "
                       f"as after the timed steps",
             "stage_seconds": {k: round(v, 4) for k, v in t.items()}}
+
+
+def reference_pcgsolver(rowptr, col, val, b, dependent):
+    """The reference's own headers/pcgsolver (PCGSolver<double>::solve: MIC(0)-preconditioned CG, one thread),
+    compiled from the reference's header into oracle/_ref/libref.so, on the symmetric liquid block of the divergence
+    system.  The as-run reference calls Eigen's CG instead; this is the one solver of the reference that can be
+    built here, timed for scale.  None when the shim is absent."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from oracle.binding import load_reference_shim
+    ref = load_reference_shim()
+    if ref is None:
+        return None
+    n = rowptr.size - 1
+    keep = ~np.asarray(dependent, bool)
+    A = sp.csr_matrix((val, col, rowptr), shape=(n, n))[keep][:, keep].tocsr()
+    A.sort_indices()
+    m = A.shape[0]
+    rp, ci, va = A.indptr.astype(np.int32), A.indices.astype(np.int32), np.ascontiguousarray(A.data, np.float64)
+    rhs = np.ascontiguousarray(b[keep], np.float64)
+    x = np.zeros(m)
+    res, it = C.c_double(0), C.c_int32(0)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    t0 = time.perf_counter()
+    ok = ref.ref_pcg_solve(m, ptr(rp), ptr(ci), ptr(va), ptr(rhs), 1e-12, 2000, ptr(x), C.byref(res), C.byref(it))
+    return {"kind": "reference", "what": "headers/pcgsolver PCGSolver<double>::solve (MIC(0) PCG, tolerance factor 1e-12, 1 thread) on "
+                                         "the liquid block of the divergence system, matrix set-up included",
+            "rows": int(m), "seconds": time.perf_counter() - t0, "iterations": int(it.value), "converged": bool(ok)}
 
 
 def stored_traffic(kernel_prefix):
