@@ -111,9 +111,10 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_pre(MgDev<CT> L, const int32_
 template <class CT>
 __device__ __forceinline__ double d_mg_second_step(const MgDev<CT> &L, const MgDev<double> &C, long long c, const double *__restrict__ in,
                                                    const double *__restrict__ out, double b) {
-    const int i = (int)(c % L.nx);
-    const long long tq = c / L.nx;
-    const int j = (int)(tq % L.ny), k = (int)(tq / L.ny);
+    // 32-bit index arithmetic: a level has fewer than 2^31 cells, and a 64-bit division costs several times a 32-bit one
+    const unsigned cu = (unsigned)c, tq = cu / (unsigned)L.nx;
+    const int i = (int)(cu - tq * (unsigned)L.nx);
+    const int k = (int)(tq / (unsigned)L.ny), j = (int)(tq - (unsigned)k * (unsigned)L.ny);
     const double v0 = out[c] + C.x[(i >> 1) + C.sy * (j >> 1) + C.sz * (k >> 1)];
     const double x1 = in[c];
     return x1 + L.a2 * (x1 - v0) + L.c2 * (double)L.inv[c] * (b - d_mg_apply(L, c, in));
@@ -162,9 +163,9 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post(MgDev<CT> F, MgDev<doubl
 #pragma unroll 2
     for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
         const long long c = F.rows[q];
-        const int i = (int)(c % F.nx);
-        const long long tq = c / F.nx;
-        const int j = (int)(tq % F.ny), k = (int)(tq / F.ny);
+        const unsigned cu = (unsigned)c, tq = cu / (unsigned)F.nx;
+        const int i = (int)(cu - tq * (unsigned)F.nx);
+        const int k = (int)(tq / (unsigned)F.ny), j = (int)(tq - (unsigned)k * (unsigned)F.ny);
         const long long pj = C.sy * (j >> 1), pk = C.sz * (k >> 1);
         const long long pc = (i >> 1) + pj + pk;
         // parents of the six neighbours (an arithmetic shift keeps -1 at -1: padded, and its coupling is 0)
@@ -200,9 +201,9 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<d
         long long cc = 0;
         if (q < n) {
             cc = C.rows[q];
-            const int I = (int)(cc % C.nx);
-            const long long tq = cc / C.nx;
-            const int J = (int)(tq % C.ny), K = (int)(tq / C.ny);
+            const unsigned cu = (unsigned)cc, tq = cu / (unsigned)C.nx;
+            const int I = (int)(cu - tq * (unsigned)C.nx);
+            const int K = (int)(tq / (unsigned)C.ny), J = (int)(tq - (unsigned)K * (unsigned)C.ny);
             const int i = 2 * I + di, j = 2 * J + dj, k = 2 * K + dk;
             if (i < F.nx && j < F.ny && k < F.nz) {
                 const long long c = (long long)i + F.sy * j + F.sz * k;
