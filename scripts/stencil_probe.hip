@@ -296,5 +296,31 @@ int main(int argc, char **argv) {
             }
         }
     }
+    // a chain of full-size stencil kernels on one stream and a chain of tiny ones (a coarse multigrid level: 3000 rows,
+    // 12 workgroups) on another: do the tiny ones hide under the large ones?
+    {
+        hipStream_t s[2];
+        for (int q = 0; q < 2; ++q) CK(hipStreamCreateWithFlags(&s[q], hipStreamNonBlocking));
+        Args big = A; big.nblk = 1024;
+        Args tiny = A; tiny.n = 3000; tiny.nblk = 16;
+        tiny.pnew = (double *)dalloc((B + 2 * pad) * 8) + pad; tiny.ap = (double *)dalloc((B + 2 * pad) * 8) + pad;
+        tiny.partial = (double *)dalloc(4096 * 8);
+        const int reps = 100;
+        auto timeit = [&](bool run_big, bool run_tiny, int tiny_per_big) {
+            CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < reps; ++r) {
+                if (run_big) k0<<<1024, BLK, 0, s[0]>>>(big);
+                if (run_tiny) for (int q = 0; q < tiny_per_big; ++q) k0<<<16, BLK, 0, s[1]>>>(tiny);
+            }
+            CK(hipDeviceSynchronize());
+            return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6 / reps;
+        };
+        for (int tpb : { 1, 4 }) {
+            timeit(true, true, tpb);
+            const double a = timeit(true, false, tpb), b = timeit(false, true, tpb), c = timeit(true, true, tpb);
+            printf("per round: 1 large kernel %.1f us; %d tiny kernels %.1f us; both on two streams %.1f us\n", a, tpb, b, c);
+        }
+    }
     return 0;
 }
