@@ -2,6 +2,8 @@
 // G2P, displacement sampling and the density field.
 #include "flip_internal.h"
 
+#include <cstdlib>
+
 // ---------------------------------------------------------------------------------------------
 // Binning.  cell(p) = floor(pos + 0.5) per axis (OpenVDB Coord::round of the index position).
 // Outside particles go to the extra bin B.
@@ -366,6 +368,136 @@ __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const 
     if ((double)dens > 1.5 * (double)da.rest) atomicAdd(da.n_over, 1);
 }
 
+// The same gather with a block of RY x RZ cells (y, z) per thread.  The kernel is bound by the particle records it
+// pulls in (each record is read by the 27 cells around it, and only the x-neighbours' reads meet in a cache), so a
+// thread that owns cells (i, j0 .. j0+RY-1, k0 .. k0+RZ-1) reads the rows around them once for all of them:
+// (RY + 2)(RZ + 2) ranges instead of 9 RY RZ.  Every cell still meets the same particles in the same order (z row, then
+// y row, then slot) and evaluates the same expressions, so the results are those of k_p2g bit for bit; the x part of
+// the weights is shared.
+template <int RY, int RZ>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_p2g_block(GridDims g, int nyb, int nzb, const int32_t *__restrict__ cell_start,
+                                                         const uint8_t *__restrict__ band, const flip_ppos *__restrict__ pm,
+                                                         const flip_pvel *__restrict__ pv, double *__restrict__ u, double *__restrict__ v,
+                                                         double *__restrict__ w, uint8_t *__restrict__ active, DensityArgs da) {
+    constexpr int R = RY * RZ;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)g.nx * nyb * nzb) return;
+    const int i = (int)(t % g.nx);
+    const long long tq = t / g.nx;
+    const int j0 = (int)(tq % nyb) * RY, k0 = (int)(tq / nyb) * RZ;
+    const float *__restrict__ phi = da.phi;
+    bool live[R];
+    float fw[R], dens[R];
+    double denom[R], ws0[R], ws1[R], ws2[R], a0[R], a1[R], a2[R];
+    bool any_live = false;
+    const double eps = (double)10e-37f; // background of the weight grid (src/FluidSimulator.cpp:32,77)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = j0 + r % RY, k = k0 + r / RY;
+        live[r] = false;
+        fw[r] = 0.f; dens[r] = 0.f; denom[r] = 1.0;
+        ws0[r] = ws1[r] = ws2[r] = eps;
+        a0[r] = a1[r] = a2[r] = 0.0;
+        if (j >= g.ny || k >= g.nz) continue;
+        const long long c = d_lid(g, i, j, k);
+        if (!(band[c] & 2)) {
+            u[c] = 0.0; v[c] = 0.0; w[c] = 0.0;
+            active[c] = 0;
+            da.density[c] = 0.f;
+            continue;
+        }
+        live[r] = true;
+        any_live = true;
+        const float pc = phi[c];
+        fw[r] = d_frac2(d_getf(g, phi, i - 1, j, k, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i, j - 1, k, da.phi_bg), pc)
+                + d_frac2(d_getf(g, phi, i, j, k - 1, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i + 1, j, k, da.phi_bg), pc)
+                + d_frac2(d_getf(g, phi, i, j + 1, k, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i, j, k + 1, da.phi_bg), pc);
+        denom[r] = (double)(fw[r] / 6) * da.vs3;
+    }
+    if (!any_live) return;
+    const double cx = (double)(g.ox + i);
+    const int i0 = i > 0 ? i - 1 : 0, i1 = i < g.nx - 1 ? i + 1 : g.nx - 1;
+    for (int kk = k0 - 1; kk <= k0 + RZ; ++kk) {
+        if (kk < 0 || kk >= g.nz) continue;
+        for (int jj = j0 - 1; jj <= j0 + RY; ++jj) {
+            if (jj < 0 || jj >= g.ny) continue;
+            bool want[R];
+            bool wanted = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int dj = jj - (j0 + r % RY), dk = kk - (k0 + r / RY);
+                want[r] = live[r] && dj >= -1 && dj <= 1 && dk >= -1 && dk <= 1;
+                wanted = wanted || want[r];
+            }
+            if (!wanted) continue;
+            const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
+            const int32_t s0 = cell_start[row + i0], s1 = cell_start[row + i1 + 1];
+            if (s0 == s1) continue;
+            const double2 *first = reinterpret_cast<const double2 *>(pm + s0);
+            double2 n0 = first[0], n1 = first[1]; // (x,y) (z, mass)
+            for (int32_t s = s0; s < s1; ++s) {
+                const double2 r0 = n0, r1 = n1;
+                if (s + 1 < s1) {
+                    const double2 *nxt = reinterpret_cast<const double2 *>(pm + s + 1);
+                    n0 = nxt[0]; n1 = nxt[1];
+                }
+                const double d0 = r0.x - cx;
+                if (fabs(d0) > 1.) continue;
+                double d1[RY], d2[RZ];
+#pragma unroll
+                for (int q = 0; q < RY; ++q) d1[q] = r0.y - (double)(g.oy + j0 + q);
+#pragma unroll
+                for (int q = 0; q < RZ; ++q) d2[q] = r1.x - (double)(g.oz + k0 + q);
+                bool pass[R];
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    pass[r] = want[r] && !(fabs(d1[r % RY]) > 1.) && !(fabs(d2[r / RY]) > 1.);
+                    any = any || pass[r];
+                }
+                if (!any) continue;
+                const double2 *vel = reinterpret_cast<const double2 *>(pv + s);
+                const double2 r2 = vel[0], r3 = vel[1]; // (vx,vy) (vz, -)
+                const float mass = __int_as_float((int)(__double_as_longlong(r1.y) & 0xffffffffLL));
+                const double hx = d_hat_in(d0);
+                const float x0 = (float)hx;
+                const float x1 = (float)d_hat_up(d0 + 0.5);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (!pass[r]) continue;
+                    const double e1 = d1[r % RY], e2 = d2[r / RY];
+                    const double hy = d_hat_in(e1), hz = d_hat_in(e2);
+                    const double wgt = hx * hy * hz;
+                    if (fw[r] > 0 && wgt > 0) {
+                        const double add = (double)0.f + wgt * (double)mass / denom[r];
+                        dens[r] = (float)((double)dens[r] + add);
+                    }
+                    const float y0 = (float)hy, z0 = (float)hz;
+                    const float y1 = (float)d_hat_up(e1 + 0.5), z1 = (float)d_hat_up(e2 + 0.5);
+                    const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
+                    if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
+                        ws0[r] = ws0[r] + w0; ws1[r] = ws1[r] + w1; ws2[r] = ws2[r] + w2;
+                        a0[r] = a0[r] + w0 * r2.x; a1[r] = a1[r] + w1 * r2.y; a2[r] = a2[r] + w2 * r3.x;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!live[r]) continue;
+        const long long c = d_lid(g, i, j0 + r % RY, k0 + r / RY);
+        u[c] = a0[r] / ws0[r];
+        v[c] = a1[r] / ws1[r];
+        w[c] = a2[r] / ws2[r];
+        active[c] = 1;
+        float dn = dens[r];
+        if (0 < fw[r] && fw[r] < 6) dn = dn > da.rest ? dn : da.rest;
+        da.density[c] = dn;
+        if ((double)dn > 1.5 * (double)da.rest) atomicAdd(da.n_over, 1);
+    }
+}
+
 static int ensure_records(flip_ctx *ctx) {
     if (ctx->prec_valid || ctx->n == 0) return 0;
     ParticlePtrs ps;
@@ -387,9 +519,26 @@ extern "C" int flip_p2g(flip_ctx *ctx) {
     DensityArgs da{ ctx->phi_fluid, ctx->density, ctx->d_counts + 2, ctx->g.phi_fluid_bg, ctx->g.rest_density,
                     pow((double)ctx->g.dx, 3) };
     FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
-    k_p2g<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->cell_start, ctx->band, packed_pos(ctx),
-                                                                   packed_vel(ctx), ctx->vel[1][0], ctx->vel[1][1], ctx->vel[1][2],
-                                                                   ctx->active, da);
+    // cells per thread in y and z.  Measured at 256^3 (8 particles per cell): 1x1 2.95 ms, 2x1 2.13, 3x1 2.07, 4x1 2.20,
+    // 1x2 2.13, 2x2 2.67, 3x2 3.66 (registers).  FLIP_P2G_BLOCK=yz selects 21, 31, 12 or 11 (the one-cell kernel) for tuning.
+    static const int shape = [] { const char *e = getenv("FLIP_P2G_BLOCK"); const int v = e ? atoi(e) : 31; return v; }();
+    const int ry = shape / 10, rz = shape % 10;
+#define FLIP_P2G_LAUNCH(RY, RZ)                                                                                              \
+    do {                                                                                                                     \
+        const int nyb = (ctx->g.ny + RY - 1) / RY, nzb = (ctx->g.nz + RZ - 1) / RZ;                                          \
+        const long long threads = (long long)ctx->g.nx * nyb * nzb;                                                          \
+        k_p2g_block<RY, RZ><<<flip_grid_blocks(threads), FLIP_BLOCK, 0, ctx->stream>>>(                                      \
+            flip_dims(ctx), nyb, nzb, ctx->cell_start, ctx->band, packed_pos(ctx), packed_vel(ctx), ctx->vel[1][0], ctx->vel[1][1], \
+            ctx->vel[1][2], ctx->active, da);                                                                                \
+    } while (0)
+    if (ry == 2 && rz == 1) FLIP_P2G_LAUNCH(2, 1);
+    else if (ry == 3 && rz == 1) FLIP_P2G_LAUNCH(3, 1);
+    else if (ry == 1 && rz == 2) FLIP_P2G_LAUNCH(1, 2);
+    else
+        k_p2g<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->cell_start, ctx->band, packed_pos(ctx),
+                                                                       packed_vel(ctx), ctx->vel[1][0], ctx->vel[1][1], ctx->vel[1][2],
+                                                                       ctx->active, da);
+#undef FLIP_P2G_LAUNCH
     FLIP_LAUNCH_CHECK();
     ctx->density_valid = true;
     for (int a = 0; a < 3; ++a) std::swap(ctx->vel[0][a], ctx->vel[1][a]);
