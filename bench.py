@@ -313,9 +313,9 @@ def main():
     traffic = None
     if rank == 0 and world == 1 and args.n == 256 and args.ppc == 8 and args.precond == "mg" and not args.full_substep:
         traffic = stored_traffic("void k_pcg_direction<true>")
-        for name in ("k_p2g", "k_g2p"):
+        for name, prefix in (("k_p2g", "void k_p2g_block"), ("k_g2p", "k_g2p")):
             if name in kernels:
-                kernels[name]["traffic"] = stored_traffic(name)
+                kernels[name]["traffic"] = stored_traffic(prefix)
     if rank == 0:
         parallelism = "single GPU"
         if world > 1:
