@@ -758,54 +758,106 @@ extern "C" int flip_particles_exchange_apply(flip_ctx *ctx, const void *recv_lo,
 // particle of shell s is at least s - 1/2 away, so the search stops as soon as the best distance found cannot be
 // beaten by the next shell, and a cell with no particle within reach keeps the background value.
 
-__device__ __forceinline__ void d_ls_range(const flip_ppos *__restrict__ pm, int32_t s0, int32_t s1, double cx, double cy,
-                                           double cz, double &best2) {
-    for (int32_t s = s0; s < s1; ++s) {
-        const double2 *rec = reinterpret_cast<const double2 *>(pm + s);
-        const double2 r0 = rec[0];
-        const double rz = rec[1].x;
-        const double dx = cx - r0.x, dy = cy - r0.y, dz = cz - rz;
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        best2 = d2 < best2 ? d2 : best2;
-    }
-}
-__global__ void k_fluid_levelset(GridDims g, float vs, double radius, double half_width, int reach,
-                                 const int32_t *__restrict__ cell_start, const flip_ppos *__restrict__ pm,
-                                 const float *__restrict__ phi_solid, float *__restrict__ phi_fluid) {
+// Cells with a particle cell within `reach` cells (Chebyshev): box dilation of the occupancy, one pass per axis.
+// A cell that is not marked keeps the background without a search.
+__global__ void k_near_x(GridDims g, int reach, const int32_t *__restrict__ cell_start, uint8_t *__restrict__ out) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.B) return;
     int i, j, k;
     d_ijk(g, c, i, j, k);
-    const double cx = (double)(g.ox + i), cy = (double)(g.oy + j), cz = (double)(g.oz + k);
-    double best2 = 1e300;
-    for (int s = 0; s <= reach; ++s) {
+    const int xa = i - reach > 0 ? i - reach : 0, xb = i + reach < g.nx - 1 ? i + reach : g.nx - 1;
+    const long long row = c - i;
+    out[c] = cell_start[row + xb + 1] > cell_start[row + xa] ? 1 : 0;
+}
+__global__ void k_near_axis(GridDims g, int axis, int reach, const uint8_t *__restrict__ in, uint8_t *__restrict__ out) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.B) return;
+    int i, j, k;
+    d_ijk(g, c, i, j, k);
+    const int pos = axis == 1 ? j : k, lim = axis == 1 ? g.ny : g.nz;
+    const long long stride = axis == 1 ? g.nx : (long long)g.nx * g.ny;
+    uint8_t m = 0;
+    for (int d = -reach; d <= reach; ++d)
+        if (pos + d >= 0 && pos + d < lim) m |= in[c + d * stride];
+    out[c] = m;
+}
+
+// One thread owns R cells of a y-column (the kernel is bound by the records it reads, and the shells of neighbouring
+// cells overlap almost entirely).  Shell s of the column is the box [i-s, i+s] x [j0-s, j0+R-1+s] x [k-s, k+s] without
+// the box of shell s-1: after it every particle within Chebyshev distance s of each of the R cells has been visited,
+// so the stopping rule holds per cell, and visiting a few particles more than a cell needs does not change a minimum.
+template <int R>
+__device__ __forceinline__ void d_ls_range(const flip_ppos *__restrict__ pm, int32_t s0, int32_t s1, double cx, const double (&cy)[R],
+                                           double cz, double (&best2)[R]) {
+    for (int32_t s = s0; s < s1; ++s) {
+        const double2 *rec = reinterpret_cast<const double2 *>(pm + s);
+        const double2 r0 = rec[0];
+        const double rz = rec[1].x;
+        const double dx = cx - r0.x, dz = cz - rz;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double dy = cy[r] - r0.y;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            best2[r] = d2 < best2[r] ? d2 : best2[r];
+        }
+    }
+}
+template <int R>
+__global__ void k_fluid_levelset(GridDims g, int nyb, float vs, double radius, double half_width, int reach,
+                                 const int32_t *__restrict__ cell_start, const flip_ppos *__restrict__ pm,
+                                 const uint8_t *__restrict__ near, const float *__restrict__ phi_solid, float *__restrict__ phi_fluid) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)g.nx * nyb * g.nz) return;
+    const int i = (int)(t % g.nx);
+    const long long tq = t / g.nx;
+    const int j0 = (int)(tq % nyb) * R, k = (int)(tq / nyb);
+    const int j1 = j0 + R - 1 < g.ny - 1 ? j0 + R - 1 : g.ny - 1; // last cell of the column inside the box
+    const double cx = (double)(g.ox + i), cz = (double)(g.oz + k);
+    double cy[R], best2[R];
+    bool search = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        cy[r] = (double)(g.oy + j0 + r);
+        best2[r] = 1e300;
+        if (j0 + r < g.ny) search = search || near[d_lid(g, i, j0 + r, k)];
+    }
+    for (int s = 0; s <= (search ? reach : -1); ++s) {
+        const int ya = j0 - s, yb = j1 + s;
         for (int dz = -s; dz <= s; ++dz) {
             const int kk = k + dz;
             if (kk < 0 || kk >= g.nz) continue;
-            for (int dy = -s; dy <= s; ++dy) {
-                const int jj = j + dy;
+            for (int jj = ya; jj <= yb; ++jj) {
                 if (jj < 0 || jj >= g.ny) continue;
                 const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
-                const bool face = dz == -s || dz == s || dy == -s || dy == s; // the whole x run lies on the shell
+                const bool face = dz == -s || dz == s || jj == ya || jj == yb; // the whole x run lies on the shell
                 if (face) {
                     const int xa = i - s > 0 ? i - s : 0, xb = i + s < g.nx - 1 ? i + s : g.nx - 1;
-                    d_ls_range(pm, cell_start[row + xa], cell_start[row + xb + 1], cx, cy, cz, best2);
+                    d_ls_range<R>(pm, cell_start[row + xa], cell_start[row + xb + 1], cx, cy, cz, best2);
                 } else {
-                    if (i - s >= 0) d_ls_range(pm, cell_start[row + i - s], cell_start[row + i - s + 1], cx, cy, cz, best2);
-                    if (i + s < g.nx) d_ls_range(pm, cell_start[row + i + s], cell_start[row + i + s + 1], cx, cy, cz, best2);
+                    if (i - s >= 0) d_ls_range<R>(pm, cell_start[row + i - s], cell_start[row + i - s + 1], cx, cy, cz, best2);
+                    if (s > 0 && i + s < g.nx) d_ls_range<R>(pm, cell_start[row + i + s], cell_start[row + i + s + 1], cx, cy, cz, best2);
                 }
             }
         }
-        // every particle of a later shell is at least s + 1/2 away
-        if (best2 <= ((double)s + 0.5) * ((double)s + 0.5)) break;
+        // every particle not visited yet is at least s + 1/2 away from each cell of the column
+        bool done = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) done = done && (j0 + r >= g.ny || best2[r] <= ((double)s + 0.5) * ((double)s + 0.5));
+        if (done) break;
     }
-    double d = half_width;
-    if (best2 < 1e299) d = sqrt(best2) - radius;
-    d = d < -half_width ? -half_width : (d > half_width ? half_width : d);
-    float f = (float)(d * (double)vs);
-    const float ps = phi_solid[c];
-    if (ps <= 0) f = f > -ps ? f : -ps;
-    phi_fluid[c] = f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (j0 + r >= g.ny) continue;
+        const long long c = d_lid(g, i, j0 + r, k);
+        double d = half_width;
+        // a particle beyond the reach of the band cannot bring the value below the band's edge
+        if (best2[r] < 1e299) d = sqrt(best2[r]) - radius;
+        d = d < -half_width ? -half_width : (d > half_width ? half_width : d);
+        float f = (float)(d * (double)vs);
+        const float ps = phi_solid[c];
+        if (ps <= 0) f = f > -ps ? f : -ps;
+        phi_fluid[c] = f;
+    }
 }
 
 extern "C" int flip_fluid_levelset_from_particles(flip_ctx *ctx, float radius_world, float half_width_voxels) {
@@ -816,9 +868,17 @@ extern "C" int flip_fluid_levelset_from_particles(flip_ctx *ctx, float radius_wo
     if (int rc = ensure_records(ctx)) return rc;
     const double radius = (double)radius_world / (double)ctx->g.dx; // index units
     const int reach = (int)ceil(radius + (double)half_width_voxels);
-    k_fluid_levelset<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->g.dx, radius,
-                                                                              (double)half_width_voxels, reach, ctx->cell_start,
-                                                                              packed_pos(ctx), ctx->phi_solid, ctx->phi_fluid);
+    const GridDims g = flip_dims(ctx);
+    const int nb = flip_grid_blocks(ctx->B);
+    // scratch: both byte arrays are rewritten by the face-fraction stage before anything reads them
+    k_near_x<<<nb, FLIP_BLOCK, 0, ctx->stream>>>(g, reach, ctx->cell_start, ctx->tmp_u8);
+    k_near_axis<<<nb, FLIP_BLOCK, 0, ctx->stream>>>(g, 1, reach, ctx->tmp_u8, ctx->seed);
+    k_near_axis<<<nb, FLIP_BLOCK, 0, ctx->stream>>>(g, 2, reach, ctx->seed, ctx->tmp_u8);
+    constexpr int R = 3; // cells per thread: 1: 3.9 ms at 256^3, 2: 2.6, 3 and 4: 2.4
+    const int nyb = (ctx->g.ny + R - 1) / R;
+    k_fluid_levelset<R><<<flip_grid_blocks((long long)ctx->g.nx * nyb * ctx->g.nz), FLIP_BLOCK, 0, ctx->stream>>>(
+        g, nyb, ctx->g.dx, radius, (double)half_width_voxels, reach, ctx->cell_start, packed_pos(ctx), ctx->tmp_u8, ctx->phi_solid,
+        ctx->phi_fluid);
     FLIP_LAUNCH_CHECK();
     ctx->density_valid = false;
     return 0;
