@@ -70,7 +70,7 @@ int flip_alloc_system(flip_ctx *c) {
             if (e == hipSuccess) c->cg_c[a] += c->pad;
         }
     }
-    A(c->cg_rows, B)
+    A(c->cg_rows, B) A(c->reg, B)
     A(c->chunk_flag, c->n_chunks + 1) A(c->chunk_list, c->n_chunks + 1)
     A(c->d_counts, 8) A(c->partial, 16 * FLIP_MAX_PCG_BLOCKS) A(c->scal, 1)
 #undef A
@@ -89,7 +89,7 @@ void flip_free_system(flip_ctx *c) {
         for (int a = 0; a < 3; ++a)
             if (c->cg_c[a]) { (void)hipFree(c->cg_c[a] - c->pad); c->cg_c[a] = nullptr; }
     }
-    dfree(c->cg_rows);
+    dfree(c->cg_rows); dfree(c->reg);
     dfree(c->chunk_flag); dfree(c->chunk_list); dfree(c->d_counts); dfree(c->partial); dfree(c->scal);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     c->events.clear();
@@ -104,6 +104,7 @@ void flip_swap_systems(flip_ctx *c) {
     std::swap(c->flags, o.flags); std::swap(c->diag, o.diag); std::swap(c->invdiag, o.invdiag); std::swap(c->rhs, o.rhs);
     std::swap(c->x, o.x); std::swap(c->r, o.r); std::swap(c->r2, o.r2); std::swap(c->z, o.z); std::swap(c->pv[0], o.pv[0]); std::swap(c->pv[1], o.pv[1]);
     std::swap(c->ap, o.ap); std::swap(c->cg_diag, o.cg_diag); std::swap(c->cg_inv, o.cg_inv);
+    std::swap(c->reg, o.reg); std::swap(c->reg_value, o.reg_value);
     std::swap(c->cg_rows, o.cg_rows); std::swap(c->chunk_flag, o.chunk_flag); std::swap(c->chunk_list, o.chunk_list);
     std::swap(c->d_counts, o.d_counts); std::swap(c->n_active_chunks, o.n_active_chunks);
     std::swap(c->partial, o.partial); std::swap(c->scal, o.scal);

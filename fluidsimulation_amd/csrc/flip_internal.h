@@ -33,6 +33,7 @@ struct flip_pcg_scalars {
     int32_t it_b;        // iteration the next update kernel runs
     int32_t done;        // set once converged (or |b| = 0)
     int32_t max_iter;
+    float creg;          // the coupling value of the rows flagged regular (see flip_ctx::reg)
     int32_t fused;       // the update kernel also pre-smooths (k_pcg_update_pre): the residual alternates between two
                          // buffers, the current one being number it_a & 1
 };
@@ -80,6 +81,8 @@ struct flip_system_set {
     double *diag = nullptr, *invdiag = nullptr, *rhs = nullptr;
     double *x = nullptr, *r = nullptr, *r2 = nullptr, *z = nullptr, *pv[2] = {}, *ap = nullptr;
     float *cg_c[3] = {};
+    uint8_t *reg = nullptr;
+    float reg_value = 0.f;
     double *cg_diag = nullptr, *cg_inv = nullptr;
     int32_t *cg_rows = nullptr, *chunk_flag = nullptr, *chunk_list = nullptr, *d_counts = nullptr;
     int32_t n_active_chunks = 0;
@@ -158,6 +161,11 @@ struct flip_ctx {
     // CG view of the system: symmetric coupling coefficient toward the low x/y/z neighbour (0 = none),
     // diagonal and Jacobi inverse; all zero on cells that are not rows of the CG system
     float *cg_c[3] = {};
+    // rows all six of whose couplings have the one common value (interior liquid cells: no solid face, no free surface
+    // next to them): the stencil kernels take the value from flip_pcg_scalars::creg and do not read the coupling
+    // arrays for them.  All zero on a slab context.
+    uint8_t *reg = nullptr;         // [B]
+    float reg_value = 0.f;
     double *cg_diag = nullptr, *cg_inv = nullptr;
     int32_t *cg_scan = nullptr;     // [B+1] scan scratch
     int32_t *cg_rows = nullptr;     // [B] cell ids of the CG rows, ascending; count in d_counts[6]

@@ -56,6 +56,7 @@ struct MgDev {
     const CT *diag, *inv;     // diagonal and its inverse (0 off the rows); level 0 reads float copies: the
                               // preconditioner does not need the last bits and these are a sixth of its traffic
     double *x, *b, *t;
+    const uint8_t *reg;              // level 0 only: rows whose six couplings all equal S->creg (nullptr: none)
     const double *b_alt;             // level 0 only: the second residual buffer of the fused update kernel
     const flip_pcg_scalars *S;       // level 0 only: says which of b / b_alt is current (nullptr: always b)
     const int32_t *rows;
@@ -69,14 +70,30 @@ __device__ __forceinline__ const double *d_mg_rhs(const MgDev<CT> &L) {
     return (L.S && L.S->fused && (L.S->it_a & 1)) ? L.b_alt : L.b;
 }
 
+// The six couplings of cell c (toward -x, +x, -y, +y, -z, +z): one common value for a row flagged regular, which
+// spares the three array reads, else from the arrays.
+template <class CT>
+__device__ __forceinline__ void d_mg_couplings(const MgDev<CT> &L, long long c, double (&a)[6]) {
+    if (L.reg && L.reg[c]) {
+        const double s = (double)L.S->creg;
+        a[0] = a[1] = a[2] = a[3] = a[4] = a[5] = s;
+    } else {
+        a[0] = (double)L.cx[c]; a[1] = (double)L.cx[c + 1];
+        a[2] = (double)L.cy[c]; a[3] = (double)L.cy[c + L.sy];
+        a[4] = (double)L.cz[c]; a[5] = (double)L.cz[c + L.sz];
+    }
+}
+
 template <class CT>
 __device__ __forceinline__ double d_mg_apply(const MgDev<CT> &L, long long c, const double *__restrict__ v) {
-    double acc = (double)L.cx[c] * v[c - 1];
-    acc += (double)L.cx[c + 1] * v[c + 1];
-    acc += (double)L.cy[c] * v[c - L.sy];
-    acc += (double)L.cy[c + L.sy] * v[c + L.sy];
-    acc += (double)L.cz[c] * v[c - L.sz];
-    acc += (double)L.cz[c + L.sz] * v[c + L.sz];
+    double a[6];
+    d_mg_couplings(L, c, a);
+    double acc = a[0] * v[c - 1];
+    acc += a[1] * v[c + 1];
+    acc += a[2] * v[c - L.sy];
+    acc += a[3] * v[c + L.sy];
+    acc += a[4] * v[c - L.sz];
+    acc += a[5] * v[c + L.sz];
     return (double)L.diag[c] * v[c] - L.scale * acc;
 }
 
@@ -94,12 +111,14 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_pre(MgDev<CT> L, const int32_
         const long long sy = L.sy, sz = L.sz;
         const double bc = b[c], ic = (double)inv[c];
         const double t0 = L.c1 * ic * bc;
-        double acc = (double)L.cx[c] * (L.c1 * (double)inv[c - 1] * b[c - 1]);
-        acc += (double)L.cx[c + 1] * (L.c1 * (double)inv[c + 1] * b[c + 1]);
-        acc += (double)L.cy[c] * (L.c1 * (double)inv[c - sy] * b[c - sy]);
-        acc += (double)L.cy[c + sy] * (L.c1 * (double)inv[c + sy] * b[c + sy]);
-        acc += (double)L.cz[c] * (L.c1 * (double)inv[c - sz] * b[c - sz]);
-        acc += (double)L.cz[c + sz] * (L.c1 * (double)inv[c + sz] * b[c + sz]);
+        double a[6];
+        d_mg_couplings(L, c, a);
+        double acc = a[0] * (L.c1 * (double)inv[c - 1] * b[c - 1]);
+        acc += a[1] * (L.c1 * (double)inv[c + 1] * b[c + 1]);
+        acc += a[2] * (L.c1 * (double)inv[c - sy] * b[c - sy]);
+        acc += a[3] * (L.c1 * (double)inv[c + sy] * b[c + sy]);
+        acc += a[4] * (L.c1 * (double)inv[c - sz] * b[c - sz]);
+        acc += a[5] * (L.c1 * (double)inv[c + sz] * b[c + sz]);
         const double At = (double)L.diag[c] * t0 - L.scale * acc;
         out[c] = t0 + L.a2 * t0 + L.c2 * ic * (bc - At);
     }
@@ -174,12 +193,14 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post(MgDev<CT> F, MgDev<doubl
         const long long pzm = (i >> 1) + pj + C.sz * ((k - 1) >> 1), pzp = (i >> 1) + pj + C.sz * ((k + 1) >> 1);
         const long long sy = F.sy, sz = F.sz;
         const double v0 = in[c] + xc[pc];
-        double acc = (double)F.cx[c] * (in[c - 1] + xc[pxm]);
-        acc += (double)F.cx[c + 1] * (in[c + 1] + xc[pxp]);
-        acc += (double)F.cy[c] * (in[c - sy] + xc[pym]);
-        acc += (double)F.cy[c + sy] * (in[c + sy] + xc[pyp]);
-        acc += (double)F.cz[c] * (in[c - sz] + xc[pzm]);
-        acc += (double)F.cz[c + sz] * (in[c + sz] + xc[pzp]);
+        double a[6];
+        d_mg_couplings(F, c, a);
+        double acc = a[0] * (in[c - 1] + xc[pxm]);
+        acc += a[1] * (in[c + 1] + xc[pxp]);
+        acc += a[2] * (in[c - sy] + xc[pym]);
+        acc += a[3] * (in[c + sy] + xc[pyp]);
+        acc += a[4] * (in[c - sz] + xc[pzm]);
+        acc += a[5] * (in[c + sz] + xc[pzp]);
         const double Av = (double)F.diag[c] * v0 - F.scale * acc;
         out[c] = v0 + F.c1 * (double)F.inv[c] * (rhs[c] - Av);
     }
@@ -421,7 +442,8 @@ static MgDev<float> mg_level0(flip_ctx *ctx) {
     { const MgCheb k = mg_cheb(); L.c1 = k.c1; L.a2 = k.a2; L.c2 = k.c2; }
     L.diag = ctx->mg_diag_f; L.inv = ctx->mg_inv_f;
     L.x = ctx->z; L.b = (wide && ctx->slab_weighted) ? ctx->dist_rw : ctx->r; L.t = ctx->ap;
-    L.b_alt = ctx->r2; L.S = ctx->scal;   // z = M^-1 r; Ap is free between the update and direction kernels
+    L.b_alt = ctx->r2; L.S = ctx->scal;
+    L.reg = ctx->reg;   // z = M^-1 r; Ap is free between the update and direction kernels
     L.rows = wide ? ctx->mg_rows : ctx->cg_rows; L.n_rows = ctx->d_counts + (wide ? 7 : 6);
     return L;
 }
@@ -435,6 +457,7 @@ static MgDev<double> mg_level(const flip_mg_level &S) {
     L.diag = S.diag; L.inv = S.inv;
     L.x = S.x; L.b = S.b; L.t = S.t;
     L.b_alt = nullptr; L.S = nullptr;
+    L.reg = nullptr;
     L.rows = S.rows; L.n_rows = S.n_rows;
     return L;
 }

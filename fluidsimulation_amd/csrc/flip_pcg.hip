@@ -202,6 +202,16 @@ __global__ void k_compact_region_rows(long long B, const int32_t *__restrict__ s
     if (scan[c + 1] > scan[c]) rows[scan[c]] = (int32_t)c;
 }
 
+__global__ void k_mark_regular(const int32_t *__restrict__ rows, const int32_t *__restrict__ n_rows, long long sy, long long sz, float S,
+                               const float *__restrict__ cx, const float *__restrict__ cy, const float *__restrict__ cz,
+                               uint8_t *__restrict__ reg) {
+    const long long n = *n_rows;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
+        const long long c = rows[q];
+        reg[c] = (cx[c] == S && cx[c + 1] == S && cy[c] == S && cy[c + sy] == S && cz[c] == S && cz[c + sz] == S) ? 1 : 0;
+    }
+}
+
 extern "C" int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1) {
     FLIP_REQUIRE(ctx, "null context");
     FLIP_REQUIRE(k0 >= 0 && k1 > k0 && k1 <= ctx->g.nz, "flip_set_slab: need 0 <= k0 < k1 <= nz");
@@ -353,6 +363,14 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     k_compact_cg_rows<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan, ctx->cg_rows);
     FLIP_LAUNCH_CHECK();
     FLIP_CHECK(hipMemcpyAsync(ctx->d_counts + 6, ctx->cg_scan + ctx->B, 4, hipMemcpyDeviceToDevice, st));
+    // rows whose six couplings are the plain face term (1 - 0) * scale
+    FLIP_CHECK(hipMemsetAsync(ctx->reg, 0, (size_t)ctx->B, st));
+    ctx->reg_value = A.scale;
+    if (A.eliminate && !ctx->slab_on) {
+        k_mark_regular<<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(ctx->cg_rows, ctx->d_counts + 6, ctx->g.nx, plane, A.scale, ctx->cg_c[0],
+                                                              ctx->cg_c[1], ctx->cg_c[2], ctx->reg);
+        FLIP_LAUNCH_CHECK();
+    }
     ctx->sys_kind = kind;
     ctx->sys_dt = dt;
     ctx->sys_s2 = A.s2;
@@ -414,6 +432,7 @@ struct PcgArgs {
     const float *tx, *ty, *tz;
     const double *diag, *invdiag, *rhs;
     const float *cgx, *cgy, *cgz;
+    const uint8_t *reg;      // rows whose couplings all equal scal->creg
     const double *cg_diag, *cg_inv;
     double *x, *r, *z, *p0, *p1, *ap;
     double *partial; // [16][FLIP_MAX_PCG_BLOCKS]
@@ -541,6 +560,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_direction(PcgArgs A) {
         const long long sy = A.sy, sz = A.sz;
         const float *__restrict__ cx = A.cgx, *__restrict__ cy = A.cgy, *__restrict__ cz = A.cgz;
         const double *__restrict__ dg = A.cg_diag;
+        const float creg = S->creg;
 #pragma unroll 2
         for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
             const long long c = A.rows[q];
@@ -548,7 +568,8 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_direction(PcgArgs A) {
                          zzp = z[c + sz];
             const double p0 = pold[c], pxm = pold[c - 1], pxp = pold[c + 1], pym = pold[c - sy], pyp = pold[c + sy],
                          pzm = pold[c - sz], pzp = pold[c + sz];
-            const float axm = cx[c], axp = cx[c + 1], aym = cy[c], ayp = cy[c + sy], azm = cz[c], azp = cz[c + sz];
+            float axm = creg, axp = creg, aym = creg, ayp = creg, azm = creg, azp = creg;
+            if (!A.reg[c]) { axm = cx[c]; axp = cx[c + 1]; aym = cy[c]; ayp = cy[c + sy]; azm = cz[c]; azp = cz[c + sz]; }
             const double d = dg[c];
             const double pc = z0 + beta * p0;
             double acc = (double)axm * (zxm + beta * pxm);
@@ -666,6 +687,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update_pre(PcgArgs A, FusedA
     long long lo, hi;
     d_row_range(A, lo, hi);
     double rr = 0.0;
+    const float creg = S->creg;
 #pragma unroll 2
     for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
         const long long c = A.rows[q];
@@ -675,12 +697,14 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update_pre(PcgArgs A, FusedA
         const double rzm = ro[c - sz] - alpha * ap[c - sz], rzp = ro[c + sz] - alpha * ap[c + sz];
         const double ic = (double)inv[c];
         const double t0 = F.c1 * ic * rc;
-        double acc = (double)cx[c] * (F.c1 * (double)inv[c - 1] * rxm);
-        acc += (double)cx[c + 1] * (F.c1 * (double)inv[c + 1] * rxp);
-        acc += (double)cy[c] * (F.c1 * (double)inv[c - sy] * rym);
-        acc += (double)cy[c + sy] * (F.c1 * (double)inv[c + sy] * ryp);
-        acc += (double)cz[c] * (F.c1 * (double)inv[c - sz] * rzm);
-        acc += (double)cz[c + sz] * (F.c1 * (double)inv[c + sz] * rzp);
+        float axm = creg, axp = creg, aym = creg, ayp = creg, azm = creg, azp = creg;
+        if (!A.reg[c]) { axm = cx[c]; axp = cx[c + 1]; aym = cy[c]; ayp = cy[c + sy]; azm = cz[c]; azp = cz[c + sz]; }
+        double acc = (double)axm * (F.c1 * (double)inv[c - 1] * rxm);
+        acc += (double)axp * (F.c1 * (double)inv[c + 1] * rxp);
+        acc += (double)aym * (F.c1 * (double)inv[c - sy] * rym);
+        acc += (double)ayp * (F.c1 * (double)inv[c + sy] * ryp);
+        acc += (double)azm * (F.c1 * (double)inv[c - sz] * rzm);
+        acc += (double)azp * (F.c1 * (double)inv[c + sz] * rzp);
         const double At = (double)F.diag_f[c] * t0 - A.s2 * acc;
         A.z[c] = t0 + F.a2 * t0 + F.c2 * ic * (rc - At);
         A.x[c] = A.x[c] + alpha * p[c];
@@ -724,6 +748,7 @@ static void fill_pcg_args(flip_ctx *ctx, PcgArgs &A) {
     A.tx = ctx->term[0]; A.ty = ctx->term[1]; A.tz = ctx->term[2];
     A.diag = ctx->diag; A.invdiag = ctx->invdiag; A.rhs = ctx->rhs;
     A.cgx = ctx->cg_c[0]; A.cgy = ctx->cg_c[1]; A.cgz = ctx->cg_c[2];
+    A.reg = ctx->reg;
     A.cg_diag = ctx->cg_diag; A.cg_inv = ctx->cg_inv;
     A.x = ctx->x; A.r = ctx->r; A.z = ctx->z; A.p0 = ctx->pv[0]; A.p1 = ctx->pv[1]; A.ap = ctx->ap;
     A.partial = ctx->partial;
@@ -781,6 +806,7 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
     h.tol2 = tol * tol;
     h.max_iter = max_iter;
     h.fused = fused ? 1 : 0;
+    h.creg = ctx->reg_value;
     FLIP_CHECK(hipMemcpyAsync(ctx->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
     PcgArgs A;
     fill_pcg_args(ctx, A);
@@ -1180,6 +1206,7 @@ extern "C" int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, 
     memset(&h, 0, sizeof h);
     h.tol2 = tol * tol;
     h.max_iter = max_iter;
+    h.creg = ctx->reg_value;
     FLIP_CHECK(hipMemcpyAsync(ctx->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
     FLIP_CHECK(hipMemsetAsync(ctx->x, 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->z, 0, (size_t)ctx->B * 8, st));

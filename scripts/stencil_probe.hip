@@ -213,6 +213,34 @@ __global__ void __launch_bounds__(BLK) k8(Args A) {
     (void)pap;
 }
 
+// K9: the production form when a per-row flag says that all six couplings have the common value (interior rows):
+// the three coupling arrays are not read for such rows
+__global__ void __launch_bounds__(BLK) k9(Args A, const uint8_t *__restrict__ reg, float S) {
+    PROLOGUE
+#pragma unroll 2
+    for (long long q = lo + threadIdx.x; q < hi; q += BLK) {
+        const long long c = A.rows[q];
+        const double z0 = z[c], zxm = z[c - 1], zxp = z[c + 1], zym = z[c - sy], zyp = z[c + sy], zzm = z[c - sz], zzp = z[c + sz];
+        const double p0 = pold[c], pxm = pold[c - 1], pxp = pold[c + 1], pym = pold[c - sy], pyp = pold[c + sy], pzm = pold[c - sz],
+                     pzp = pold[c + sz];
+        float axm = S, axp = S, aym = S, ayp = S, azm = S, azp = S;
+        if (!reg[c]) { axm = cx[c]; axp = cx[c + 1]; aym = cy[c]; ayp = cy[c + sy]; azm = cz[c]; azp = cz[c + sz]; }
+        const double d = dg[c];
+        const double pc = z0 + beta * p0;
+        double acc = (double)axm * (zxm + beta * pxm);
+        acc += (double)axp * (zxp + beta * pxp);
+        acc += (double)aym * (zym + beta * pym);
+        acc += (double)ayp * (zyp + beta * pyp);
+        acc += (double)azm * (zzm + beta * pzm);
+        acc += (double)azp * (zzp + beta * pzp);
+        const double s = d * pc - A.s2 * acc;
+        A.pnew[c] = pc;
+        A.ap[c] = s;
+        pap += pc * s;
+    }
+    EPILOGUE
+}
+
 template <class K>
 static void run(const char *name, K kern, Args A, int nblk, double bytes) {
     hipEvent_t e0, e1;
@@ -261,6 +289,20 @@ int main(int argc, char **argv) {
         run("k3 32-bit ids", k3, A, nblk, bytes);
         run("k4 own cell only", k4, A, nblk, bytes);
         run("k5 x neighbours by shuffle", k5, A, nblk, bytes);
+    }
+    {
+        uint8_t *reg = (uint8_t *)dalloc(B);
+        CK(hipMemset(reg, 1, B));
+        A.nblk = 1024;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int w = 0; w < 5; ++w) k9<<<1024, BLK>>>(A, reg, 0.5f);
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < 200; ++r) k9<<<1024, BLK>>>(A, reg, 0.5f);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("k9 couplings by flag (all regular)  %8.2f us  %6.2f TB/s (53 B/row)\n", ms * 1e3 / 200, bytes / (ms * 1e3 / 200) * 1e-6);
     }
     {
         const int g1 = (int)((n + BLK - 1) / BLK);
