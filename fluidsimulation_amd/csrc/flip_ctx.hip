@@ -27,8 +27,10 @@ extern "C" const char *flip_last_error(const flip_ctx *ctx) { return ctx ? ctx->
 template <class T>
 static hipError_t dalloc(T **p, int64_t count) {
     hipError_t e = hipMalloc((void **)p, (size_t)(count > 0 ? count : 1) * sizeof(T));
-    if (e != hipSuccess) return e;
-    return hipMemset(*p, 0, (size_t)(count > 0 ? count : 1) * sizeof(T));
+    if (e != hipSuccess) { *p = nullptr; return e; }
+    e = hipMemset(*p, 0, (size_t)(count > 0 ? count : 1) * sizeof(T));
+    if (e != hipSuccess) { (void)hipFree(*p); *p = nullptr; } // callers offset or free only pointers that are fully set up
+    return e;
 }
 template <class T>
 static void dfree(T *&p) {
@@ -47,6 +49,8 @@ static void free_particles(flip_ctx *c) {
     dfree(c->slot_key);
     dfree(c->stage);
     dfree(c->prec);
+    dfree(c->pcell);
+    dfree(c->sub_slot);
     c->cap = 0;
 }
 
@@ -127,7 +131,7 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
         if (c->pair_stream[q]) (void)hipStreamDestroy(c->pair_stream[q]);
     for (int q = 0; q < 3; ++q)
         if (c->pair_event[q]) (void)hipEventDestroy(c->pair_event[q]);
-    dfree(c->cell_start); dfree(c->cell_fill); dfree(c->scan_tmp);
+    dfree(c->cell_start); dfree(c->cell_fill); dfree(c->sub_start); dfree(c->scan_tmp);
     dfree(c->phi_fluid); dfree(c->phi_solid); dfree(c->phi_obj);
     for (int b = 0; b < 4; ++b)
         for (int a = 0; a < 3; ++a) dfree(c->vel[b][a]);
@@ -152,6 +156,7 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     FLIP_REQUIRE(desc->nx > 0 && desc->ny > 0 && desc->nz > 0, "flip_ctx_create: empty box");
     FLIP_REQUIRE((int64_t)desc->nx * desc->ny * desc->nz < (int64_t)2000000000, "flip_ctx_create: box too large for 32-bit cell ids");
     FLIP_REQUIRE(desc->dx > 0.f, "flip_ctx_create: dx must be positive");
+    FLIP_REQUIRE(8LL * desc->nx * 4 + 16 <= 60 * 1024, "flip_ctx_create: box too wide (nx) for the per-row half-cell index in LDS");
     int ndev = 0;
     FLIP_CHECK(hipGetDeviceCount(&ndev));
     FLIP_REQUIRE(ndev > 0, "flip_ctx_create: no HIP device (this library has no CPU path)");
@@ -169,7 +174,7 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     hipError_t e = hipSuccess;
 #define A(ptr, count)                                  \
     if (e == hipSuccess) e = dalloc(&(ptr), (count));
-    A(c->cell_start, B + 2) A(c->cell_fill, B + 1)
+    A(c->cell_start, B + 2) A(c->cell_fill, B + 1) A(c->sub_start, 8 * B + 1)
     A(c->phi_fluid, B) A(c->phi_solid, B) A(c->phi_obj, B)
     for (int b = 0; b < 4; ++b)
         for (int a = 0; a < 3; ++a) A(c->vel[b][a], B)
@@ -187,10 +192,14 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     A(c->cg_scan, B + 1)
     A(c->d_vmax, 3 * FLIP_MAX_PCG_BLOCKS)
 #undef A
-    if (e == hipSuccess && flip_alloc_system(c) != 0) e = hipErrorOutOfMemory;
     if (e != hipSuccess) {
         flip_ctx_destroy(c);
         return flip_fail_hip(nullptr, e, "hipMalloc of the dense fields", __FILE__, __LINE__);
+    }
+    if (flip_alloc_system(c) != 0) { // keep the text flip_alloc_system recorded
+        g_create_error = c->err;
+        flip_ctx_destroy(c);
+        return 2;
     }
     // phi fields start at their backgrounds ("no fluid", "all open") until uploaded
     {
@@ -330,6 +339,8 @@ static int ensure_particle_capacity(flip_ctx *ctx, int64_t n) {
     if (e == hipSuccess) e = dalloc(&ctx->slot_key, cap + 1);
     if (e == hipSuccess) e = dalloc(&ctx->stage, cap * 6);
     if (e == hipSuccess) e = dalloc(&ctx->prec, cap);
+    if (e == hipSuccess) e = dalloc(&ctx->pcell, cap);
+    if (e == hipSuccess) e = dalloc(&ctx->sub_slot, cap);
     if (e != hipSuccess) return flip_fail_hip(ctx, e, "hipMalloc of the particle arrays", __FILE__, __LINE__);
     ctx->cap = cap;
     return 0;

@@ -118,7 +118,11 @@ struct flip_ctx {
     int32_t *scan_tmp = nullptr;    // block sums of the scan
     int64_t scan_tmp_len = 0;
     double *stage = nullptr;        // [cap*3] upload/download staging (AoS)
-    flip_prec *prec = nullptr;      // [cap] x 64 bytes: flip_ppos[cap] followed by flip_pvel[cap], the gather kernels' copy
+    flip_prec *prec = nullptr;      // [cap] x 64 bytes: flip_ppos[cap] followed by flip_pvel[cap], the gather kernels' copy,
+                                    // sorted by half cell (see k_subrow_pack)
+    flip_ppos *pcell = nullptr;     // [cap] positions + mass in the primary (cell) order, for the level-set search
+    int32_t *sub_start = nullptr;   // [8 B + 1] run boundaries of the half-cell order: per grid row 4 sub-rows of 2 nx
+    int32_t *sub_slot = nullptr;    // [cap] place of primary slot s in the half-cell order
     bool prec_valid = false;
     bool binned = false;
     bool slots_valid = false;       // cell_start still describes the slot order (no upload / exchange since the sort)

@@ -116,7 +116,7 @@ struct ParticlePtrs {
     int32_t *pid;
 };
 __global__ void k_reorder(long long n, const int32_t *__restrict__ slot_src, const int32_t *__restrict__ slot_key,
-                          ParticlePtrs src, ParticlePtrs dst, flip_ppos *__restrict__ pm, flip_pvel *__restrict__ pv) {
+                          ParticlePtrs src, ParticlePtrs dst, flip_ppos *__restrict__ pcell) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const int32_t o = slot_src[s];
@@ -128,24 +128,131 @@ __global__ void k_reorder(long long n, const int32_t *__restrict__ slot_src, con
     dst.pid[s] = slot_key[s];
     flip_ppos a;
     a.x = v[0]; a.y = v[1]; a.z = v[2]; a.mass = m; a.pad0 = 0.f;
-    flip_pvel b;
-    b.vx = v[3]; b.vy = v[4]; b.vz = v[5]; b.pad1 = 0.0;
-    pm[s] = a;
-    pv[s] = b;
+    pcell[s] = a;
 }
-// refresh of the packed records when the SoA arrays changed without a re-sort (velocities after G2P)
-__global__ void k_pack_records(long long n, ParticlePtrs src, flip_ppos *__restrict__ pm, flip_pvel *__restrict__ pv) {
+
+// ---------------------------------------------------------------------------------------------
+// Gather order.  A cell c gathers the particles with |pos - c| <= 1 per axis (the atlas query box of
+// src/Functors.cpp:21-24).  Cut every cell in two along each axis: the box of c is then exactly 4 x 4 x 4 half cells
+// -- the upper half of the cells at c-1, both halves at c, the lower half at c+1 -- except for a particle at exactly
+// c+1, whose weights are all zero (hat(1) = hat(1.5) = 0) and which the reference therefore skips as well.  So the
+// gather kernels read a second copy of the particle records that is sorted by half cell: grid row (k, j), then z half,
+// then y half, then 2*i + x half, then upload index.  The support of a cell is 16 contiguous runs of that copy
+// (sub_start holds the run boundaries, 8 entries per cell), every record in them contributes, and no record outside
+// them does: no support test, no rejected visit.  The primary SoA order (cell, upload index) is untouched; a grid row
+// occupies the same slot range in both orders.
+//
+// "Upper half" uses the expression the gather of the cell above evaluates for the lower edge of its box,
+// pos - (n+1) >= -1, so the classification agrees with that test to the last bit.  (The mirrored statement for the
+// upper edge, pos - (n-1) < 1 for every particle of a lower half, can only fail for a coordinate within 2^-53 of an
+// integer below 1 in magnitude, where the subtraction rounds; such a particle carries a weight of 2^-53.)
+__device__ __forceinline__ int d_upper_half(double p, int n_index) { return (p - (double)(n_index + 1)) >= -1.0 ? 1 : 0; }
+
+__device__ __forceinline__ int d_sub_index(const GridDims &g, double x, double y, double z, int ci, int j, int k) {
+    const int hx = d_upper_half(x, g.ox + ci), hy = d_upper_half(y, g.oy + j), hz = d_upper_half(z, g.oz + k);
+    return (hz * 2 + hy) * (2 * g.nx) + 2 * ci + hx;
+}
+
+// One workgroup per grid row (j, k): counts the row's particles per half cell in LDS, scans, writes the row's 8 nx
+// entries of sub_start, and copies the records to their place in the half-cell order.  The rank of a particle inside
+// its half cell is the number of earlier slots of its cell that fall into the same half cell: the cell's slots are
+// sorted by upload index, so the half-cell order is too.  tmp_q / tmp_rank: two int32 scratch arrays over the slots.
+__global__ void __launch_bounds__(FLIP_BLOCK) k_subrow_pack(GridDims g, const int32_t *__restrict__ cell_start, ParticlePtrs src,
+                                                           int32_t *__restrict__ sub_start, int32_t *__restrict__ sub_slot,
+                                                           int32_t *__restrict__ tmp_q, int32_t *__restrict__ tmp_rank,
+                                                           flip_ppos *__restrict__ pm, flip_pvel *__restrict__ pv) {
+    extern __shared__ int32_t lds[]; // [8 nx] counts, then exclusive offsets; [4] wave totals
+    const int nsub = 8 * g.nx;
+    const long long row = blockIdx.x;
+    const long long c0 = row * g.nx;
+    const int32_t r0 = cell_start[c0], r1 = cell_start[c0 + g.nx];
+    int32_t *__restrict__ out = sub_start + row * nsub;
+    const int tid = threadIdx.x;
+    const bool last = row == (long long)gridDim.x - 1;
+    if (r0 == r1) {
+        for (int q = tid; q < nsub; q += FLIP_BLOCK) out[q] = r0;
+        if (last && tid == 0) out[nsub] = r1;
+        return;
+    }
+    for (int q = tid; q < nsub; q += FLIP_BLOCK) lds[q] = 0;
+    __syncthreads();
+    const int j = (int)(row % g.ny), k = (int)(row / g.ny);
+    for (int32_t s = r0 + tid; s < r1; s += FLIP_BLOCK) {
+        const double x = src.a[0][s], y = src.a[1][s], z = src.a[2][s];
+        const int ci = (int)floor(x + 0.5) - g.ox;
+        const int q = d_sub_index(g, x, y, z, ci, j, k);
+        int32_t rank = 0;
+        for (int32_t t = cell_start[c0 + ci]; t < s; ++t)
+            rank += d_sub_index(g, src.a[0][t], src.a[1][t], src.a[2][t], ci, j, k) == q ? 1 : 0;
+        atomicAdd(&lds[q], 1); // integer: the totals do not depend on the order of arrival
+        tmp_q[s] = q;
+        tmp_rank[s] = rank;
+    }
+    __syncthreads();
+    // exclusive scan of lds[0 .. nsub): a run of consecutive entries per thread, wave scan of the run totals
+    const int items = (nsub + FLIP_BLOCK - 1) / FLIP_BLOCK;
+    const int b0 = tid * items, b1 = b0 + items < nsub ? b0 + items : nsub;
+    int32_t sum = 0;
+    for (int q = b0; q < b1; ++q) sum += lds[q];
+    const int lane = tid & 63, wave = tid >> 6;
+    int32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t t = __shfl_up(incl, off, FLIP_WAVE);
+        if (lane >= off) incl += t;
+    }
+    int32_t *wave_tot = lds + nsub;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int32_t run = r0 + incl - sum;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
+    for (int q = b0; q < b1; ++q) {
+        const int32_t v = lds[q];
+        lds[q] = run;
+        run += v;
+    }
+    __syncthreads();
+    for (int q = tid; q < nsub; q += FLIP_BLOCK) out[q] = lds[q];
+    if (last && tid == 0) out[nsub] = r1;
+    for (int32_t s = r0 + tid; s < r1; s += FLIP_BLOCK) {
+        const int32_t d = lds[tmp_q[s]] + tmp_rank[s];
+        sub_slot[s] = d;
+        flip_ppos a;
+        a.x = src.a[0][s]; a.y = src.a[1][s]; a.z = src.a[2][s]; a.mass = src.mass[s]; a.pad0 = 0.f;
+        flip_pvel b;
+        b.vx = src.a[3][s]; b.vy = src.a[4][s]; b.vz = src.a[5][s]; b.pad1 = 0.0;
+        pm[d] = a;
+        pv[d] = b;
+    }
+}
+// refresh of the packed records when the SoA arrays changed without a re-sort (velocities after G2P); n_inside_ptr:
+// the number of particles inside the box, the only ones the half-cell order holds
+__global__ void k_pack_records(long long n, const int32_t *__restrict__ n_inside_ptr, ParticlePtrs src,
+                               const int32_t *__restrict__ sub_slot, flip_ppos *__restrict__ pm, flip_pvel *__restrict__ pv,
+                               flip_ppos *__restrict__ pcell) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     flip_ppos a;
     a.x = src.a[0][s]; a.y = src.a[1][s]; a.z = src.a[2][s]; a.mass = src.mass[s]; a.pad0 = 0.f;
+    pcell[s] = a;
+    if (s >= *n_inside_ptr) return;
     flip_pvel b;
     b.vx = src.a[3][s]; b.vy = src.a[4][s]; b.vz = src.a[5][s]; b.pad1 = 0.0;
-    pm[s] = a;
-    pv[s] = b;
+    const int32_t d = sub_slot[s];
+    pm[d] = a;
+    pv[d] = b;
 }
+static ParticlePtrs particle_ptrs(flip_ctx *ctx, int buffer) {
+    ParticlePtrs ps;
+    for (int q = 0; q < 6; ++q) ps.a[q] = ctx->p[buffer][q];
+    ps.mass = ctx->mass[buffer];
+    ps.pid = ctx->pid[buffer];
+    return ps;
+}
+
 static inline flip_ppos *packed_pos(flip_ctx *ctx) { return reinterpret_cast<flip_ppos *>(ctx->prec); }
 static inline flip_pvel *packed_vel(flip_ctx *ctx) { return reinterpret_cast<flip_pvel *>(reinterpret_cast<flip_ppos *>(ctx->prec) + ctx->cap); }
+static inline size_t subrow_lds_bytes(const flip_ctx *ctx) { return ((size_t)8 * ctx->g.nx + 4) * sizeof(int32_t); }
 
 // Occupancy bands: bit0 = within 1 cell of a particle cell, bit1 = within 2 (Chebyshev distance).
 // Box dilation is separable: one pass per axis.
@@ -218,11 +325,16 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
         for (int q = 0; q < 6; ++q) { ps.a[q] = ctx->p[src][q]; pd.a[q] = ctx->p[dst][q]; }
         ps.mass = ctx->mass[src]; pd.mass = ctx->mass[dst];
         ps.pid = ctx->pid[src]; pd.pid = ctx->pid[dst];
-        k_reorder<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->slot_src, ctx->slot_key, ps, pd, packed_pos(ctx), packed_vel(ctx));
+        k_reorder<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->slot_src, ctx->slot_key, ps, pd, ctx->pcell);
         FLIP_LAUNCH_CHECK();
         ctx->cur = dst;
-        ctx->prec_valid = true;
     }
+    // the half-cell ordered copy of the records and its index (also with no particles: the gathers read sub_start)
+    k_subrow_pack<<<(int)((long long)ctx->g.ny * ctx->g.nz), FLIP_BLOCK, subrow_lds_bytes(ctx), st>>>(
+        g, ctx->cell_start, particle_ptrs(ctx, ctx->cur), ctx->sub_start, ctx->sub_slot, ctx->slot_key, ctx->slot_src, packed_pos(ctx),
+        packed_vel(ctx));
+    FLIP_LAUNCH_CHECK();
+    ctx->prec_valid = true;
     k_band_x<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, ctx->cell_start, ctx->band);
     FLIP_LAUNCH_CHECK();
     k_band_axis<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, 1, ctx->band, ctx->tmp_u8);
@@ -274,14 +386,17 @@ extern "C" int flip_binning_download(flip_ctx *ctx, int32_t *cell_id, int32_t *c
 }
 
 // ---------------------------------------------------------------------------------------------
-// P2G gather (src/FluidSimulator.cpp:71-118, src/Functors.cpp:10-45, kernel :1361-1371).
-// One thread per cell of the band.  The particles of the three x-neighbours of a grid row are
-// contiguous in the sorted arrays, so each (dy,dz) row is one slot range.  Accumulation order:
-// ascending neighbour cell id, sorted slots within a cell.
-
-// The same walk also yields the cell's density (src/FluidSimulator.cpp:625-652, src/Functors.cpp:216-266):
-// the level set does not change between the two reference calls, so the second pass over the particles is
-// saved.  flip_density() launches k_density only when the fused result is stale.
+// P2G gather (src/FluidSimulator.cpp:71-118, src/Functors.cpp:10-45, kernel :1361-1371) and the density field
+// (src/FluidSimulator.cpp:625-652, src/Functors.cpp:216-266; the level set does not change between the two reference
+// calls, so one walk over the particles serves both; flip_density() launches the density-only form when the fused
+// result is stale).
+//
+// One thread per cell of the band.  Its particles are the 16 runs of the half-cell order described above.  The runs
+// of a lane are 0 to ~10 records long and differ from lane to lane, so a loop per run would idle most of the wave most
+// of the time; instead every lane walks ONE flat sequence -- its non-empty runs back to back, their (first, end) pairs
+// parked in LDS because the run number is a per-lane variable -- and the wave iterates max-over-lanes of the total,
+// which at 8 particles per cell is 64 +- 8.  The next record is requested before the current one is consumed.
+// Accumulation order = run order = the order stated at d_upper_half.
 struct DensityArgs {
     const float *phi;
     float *density;
@@ -290,17 +405,21 @@ struct DensityArgs {
     double vs3;
 };
 
-__global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const uint8_t *__restrict__ band,
-                      const flip_ppos *__restrict__ pm, const flip_pvel *__restrict__ pv, double *__restrict__ u,
-                      double *__restrict__ v, double *__restrict__ w, uint8_t *__restrict__ active, DensityArgs da) {
+#define FLIP_GATHER_RUNS 16
+template <bool P2G>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, const int32_t *__restrict__ sub_start, const uint8_t *__restrict__ band,
+                                                      const flip_ppos *__restrict__ pm, const flip_pvel *__restrict__ pv,
+                                                      double *__restrict__ u, double *__restrict__ v, double *__restrict__ w,
+                                                      uint8_t *__restrict__ active, DensityArgs da) {
+    __shared__ int2 runs[FLIP_GATHER_RUNS][FLIP_BLOCK];
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.B) return;
     if (!(band[c] & 2)) {
-        u[c] = 0.0; v[c] = 0.0; w[c] = 0.0;
-        active[c] = 0;
+        if (P2G) { u[c] = 0.0; v[c] = 0.0; w[c] = 0.0; active[c] = 0; }
         da.density[c] = 0.f;
         return;
     }
+    const int tid = threadIdx.x;
     int i, j, k;
     d_ijk(g, c, i, j, k);
     const float *__restrict__ phi = da.phi;
@@ -310,45 +429,78 @@ __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const 
                      + d_frac2(d_getf(g, phi, i, j + 1, k, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i, j, k + 1, da.phi_bg), pc);
     const double denom = (double)(fw / 6) * da.vs3;
     const bool with_density = fw > 0;
+    int nr = 0;
+    if (P2G || with_density) {
+        const int sxa = i > 0 ? 2 * i - 1 : 0, sxb = i < g.nx - 1 ? 2 * i + 2 : 2 * g.nx - 1;
+        const int nx2 = 2 * g.nx;
+#pragma unroll
+        for (int dk = -1; dk <= 1; ++dk) {
+            const int kk = k + dk;
+            if (kk < 0 || kk >= g.nz) continue;
+#pragma unroll
+            for (int dj = -1; dj <= 1; ++dj) {
+                const int jj = j + dj;
+                if (jj < 0 || jj >= g.ny) continue;
+                const long long rowbase = ((long long)kk * g.ny + jj) * (4LL * nx2);
+#pragma unroll
+                for (int hz = (dk < 0 ? 1 : 0); hz <= (dk > 0 ? 0 : 1); ++hz) {
+#pragma unroll
+                    for (int hy = (dj < 0 ? 1 : 0); hy <= (dj > 0 ? 0 : 1); ++hy) {
+                        const int32_t *row = sub_start + rowbase + (long long)(hz * 2 + hy) * nx2;
+                        const int32_t s0 = row[sxa], s1 = row[sxb + 1];
+                        if (s0 < s1) { runs[nr][tid] = make_int2(s0, s1); ++nr; }
+                    }
+                }
+            }
+        }
+    }
     float dens = 0.f;
     const double eps = (double)10e-37f; // background of the weight grid (src/FluidSimulator.cpp:32,77)
     double ws0 = eps, ws1 = eps, ws2 = eps, a0 = 0.0, a1 = 0.0, a2 = 0.0;
     const double cx = (double)(g.ox + i), cy = (double)(g.oy + j), cz = (double)(g.oz + k);
-    const int i0 = i > 0 ? i - 1 : 0, i1 = i < g.nx - 1 ? i + 1 : g.nx - 1;
-    for (int kk = k - 1; kk <= k + 1; ++kk) {
-        if (kk < 0 || kk >= g.nz) continue;
-        for (int jj = j - 1; jj <= j + 1; ++jj) {
-            if (jj < 0 || jj >= g.ny) continue;
-            const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
-            const int32_t s0 = cell_start[row + i0], s1 = cell_start[row + i1 + 1];
-            if (s0 == s1) continue;
-            // Every lane walks its own slot range, so each 16-byte load of the wave asks for up to 64 different
-            // lines and the loop is bound by that line traffic: position and mass come from the 32-byte position
-            // half (two consecutive slots share a line), the velocity half is fetched only by the lanes whose particle
-            // lies within the kernel's support (about 30 %), and the next position is requested before the current
-            // one is consumed.
-            const double2 *first = reinterpret_cast<const double2 *>(pm + s0);
-            double2 n0 = first[0], n1 = first[1]; // (x,y) (z, mass)
-            for (int32_t s = s0; s < s1; ++s) {
-                const double2 r0 = n0, r1 = n1;
-                if (s + 1 < s1) {
-                    const double2 *nxt = reinterpret_cast<const double2 *>(pm + s + 1);
-                    n0 = nxt[0]; n1 = nxt[1];
+    if (nr > 0) {
+        int r = 0;
+        int2 cur = runs[0][tid];
+        int32_t s = cur.x, e = cur.y;
+        const double2 *rec = reinterpret_cast<const double2 *>(pm + s);
+        double2 p0 = rec[0], p1 = rec[1]; // (x, y) (z, mass)
+        double2 q0 = make_double2(0.0, 0.0), q1 = q0;
+        if (P2G) {
+            const double2 *vel = reinterpret_cast<const double2 *>(pv + s);
+            q0 = vel[0]; q1 = vel[1]; // (vx, vy) (vz, -)
+        }
+        bool live = true;
+        while (live) {
+            const double2 r0 = p0, r1 = p1, r2 = q0, r3 = q1;
+            // step to the next record of the flat sequence and request it
+            ++s;
+            if (s == e) {
+                ++r;
+                live = r < nr;
+                if (live) {
+                    cur = runs[r][tid];
+                    s = cur.x; e = cur.y;
                 }
-                const double d0 = r0.x - cx, d1 = r0.y - cy, d2 = r1.x - cz;
-                if (fabs(d0) > 1. || fabs(d1) > 1. || fabs(d2) > 1.) continue;
-                const double2 *vel = reinterpret_cast<const double2 *>(pv + s);
-                const double2 r2 = vel[0], r3 = vel[1]; // (vx,vy) (vz, -)
+            }
+            if (live) {
+                rec = reinterpret_cast<const double2 *>(pm + s);
+                p0 = rec[0]; p1 = rec[1];
+                if (P2G) {
+                    const double2 *vel = reinterpret_cast<const double2 *>(pv + s);
+                    q0 = vel[0]; q1 = vel[1];
+                }
+            }
+            const double d0 = r0.x - cx, d1 = r0.y - cy, d2 = r1.x - cz;
+            // inside the support the hat function is 1 - |x| (1 + x for a negative x is the same IEEE operation), and the
+            // shifted argument x + 1/2 lies in [-1/2, 3/2], so only its upper cut-off needs a test
+            const double hx = d_hat_in(d0), hy = d_hat_in(d1), hz = d_hat_in(d2);
+            const double wgt = hx * hy * hz;
+            if (with_density && wgt > 0) {
                 const float mass = __int_as_float((int)(__double_as_longlong(r1.y) & 0xffffffffLL));
-                // the kernel loop is bound by instruction issue: inside the support the hat function is 1 - |x|
-                // (1 + x for a negative x is the same IEEE operation as 1 - |x|), and the shifted argument
-                // x + 1/2 lies in [-1/2, 3/2], so only its upper cut-off needs a test
-                const double hx = d_hat_in(d0), hy = d_hat_in(d1), hz = d_hat_in(d2);
-                const double wgt = hx * hy * hz;
-                if (with_density && wgt > 0) {
-                    const double add = (double)0.f + wgt * (double)mass / denom;
-                    dens = (float)((double)dens + add);
-                }
+                const double add = (double)0.f + wgt * (double)mass / denom;
+                dens = (float)((double)dens + add);
+            }
+            if (P2G) {
                 const float x0 = (float)hx, y0 = (float)hy, z0 = (float)hz;
                 const float x1 = (float)d_hat_up(d0 + 0.5), y1 = (float)d_hat_up(d1 + 0.5), z1 = (float)d_hat_up(d2 + 0.5);
                 const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
@@ -359,152 +511,21 @@ __global__ void k_p2g(GridDims g, const int32_t *__restrict__ cell_start, const 
             }
         }
     }
-    u[c] = a0 / ws0;
-    v[c] = a1 / ws1;
-    w[c] = a2 / ws2;
-    active[c] = 1;
+    if (P2G) {
+        u[c] = a0 / ws0;
+        v[c] = a1 / ws1;
+        w[c] = a2 / ws2;
+        active[c] = 1;
+    }
     if (0 < fw && fw < 6) dens = dens > da.rest ? dens : da.rest;
     da.density[c] = dens;
     if ((double)dens > 1.5 * (double)da.rest) atomicAdd(da.n_over, 1);
 }
 
-// The same gather with a block of RY x RZ cells (y, z) per thread.  The kernel is bound by the particle records it
-// pulls in (each record is read by the 27 cells around it, and only the x-neighbours' reads meet in a cache), so a
-// thread that owns cells (i, j0 .. j0+RY-1, k0 .. k0+RZ-1) reads the rows around them once for all of them:
-// (RY + 2)(RZ + 2) ranges instead of 9 RY RZ.  Every cell still meets the same particles in the same order (z row, then
-// y row, then slot) and evaluates the same expressions, so the results are those of k_p2g bit for bit; the x part of
-// the weights is shared.
-template <int RY, int RZ>
-__global__ void __launch_bounds__(FLIP_BLOCK) k_p2g_block(GridDims g, int nyb, int nzb, const int32_t *__restrict__ cell_start,
-                                                         const uint8_t *__restrict__ band, const flip_ppos *__restrict__ pm,
-                                                         const flip_pvel *__restrict__ pv, double *__restrict__ u, double *__restrict__ v,
-                                                         double *__restrict__ w, uint8_t *__restrict__ active, DensityArgs da) {
-    constexpr int R = RY * RZ;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)g.nx * nyb * nzb) return;
-    const int i = (int)(t % g.nx);
-    const long long tq = t / g.nx;
-    const int j0 = (int)(tq % nyb) * RY, k0 = (int)(tq / nyb) * RZ;
-    const float *__restrict__ phi = da.phi;
-    bool live[R];
-    float fw[R], dens[R];
-    double denom[R], ws0[R], ws1[R], ws2[R], a0[R], a1[R], a2[R];
-    bool any_live = false;
-    const double eps = (double)10e-37f; // background of the weight grid (src/FluidSimulator.cpp:32,77)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int j = j0 + r % RY, k = k0 + r / RY;
-        live[r] = false;
-        fw[r] = 0.f; dens[r] = 0.f; denom[r] = 1.0;
-        ws0[r] = ws1[r] = ws2[r] = eps;
-        a0[r] = a1[r] = a2[r] = 0.0;
-        if (j >= g.ny || k >= g.nz) continue;
-        const long long c = d_lid(g, i, j, k);
-        if (!(band[c] & 2)) {
-            u[c] = 0.0; v[c] = 0.0; w[c] = 0.0;
-            active[c] = 0;
-            da.density[c] = 0.f;
-            continue;
-        }
-        live[r] = true;
-        any_live = true;
-        const float pc = phi[c];
-        fw[r] = d_frac2(d_getf(g, phi, i - 1, j, k, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i, j - 1, k, da.phi_bg), pc)
-                + d_frac2(d_getf(g, phi, i, j, k - 1, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i + 1, j, k, da.phi_bg), pc)
-                + d_frac2(d_getf(g, phi, i, j + 1, k, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i, j, k + 1, da.phi_bg), pc);
-        denom[r] = (double)(fw[r] / 6) * da.vs3;
-    }
-    if (!any_live) return;
-    const double cx = (double)(g.ox + i);
-    const int i0 = i > 0 ? i - 1 : 0, i1 = i < g.nx - 1 ? i + 1 : g.nx - 1;
-    for (int kk = k0 - 1; kk <= k0 + RZ; ++kk) {
-        if (kk < 0 || kk >= g.nz) continue;
-        for (int jj = j0 - 1; jj <= j0 + RY; ++jj) {
-            if (jj < 0 || jj >= g.ny) continue;
-            bool want[R];
-            bool wanted = false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int dj = jj - (j0 + r % RY), dk = kk - (k0 + r / RY);
-                want[r] = live[r] && dj >= -1 && dj <= 1 && dk >= -1 && dk <= 1;
-                wanted = wanted || want[r];
-            }
-            if (!wanted) continue;
-            const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
-            const int32_t s0 = cell_start[row + i0], s1 = cell_start[row + i1 + 1];
-            if (s0 == s1) continue;
-            const double2 *first = reinterpret_cast<const double2 *>(pm + s0);
-            double2 n0 = first[0], n1 = first[1]; // (x,y) (z, mass)
-            for (int32_t s = s0; s < s1; ++s) {
-                const double2 r0 = n0, r1 = n1;
-                if (s + 1 < s1) {
-                    const double2 *nxt = reinterpret_cast<const double2 *>(pm + s + 1);
-                    n0 = nxt[0]; n1 = nxt[1];
-                }
-                const double d0 = r0.x - cx;
-                if (fabs(d0) > 1.) continue;
-                double d1[RY], d2[RZ];
-#pragma unroll
-                for (int q = 0; q < RY; ++q) d1[q] = r0.y - (double)(g.oy + j0 + q);
-#pragma unroll
-                for (int q = 0; q < RZ; ++q) d2[q] = r1.x - (double)(g.oz + k0 + q);
-                bool pass[R];
-                bool any = false;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    pass[r] = want[r] && !(fabs(d1[r % RY]) > 1.) && !(fabs(d2[r / RY]) > 1.);
-                    any = any || pass[r];
-                }
-                if (!any) continue;
-                const double2 *vel = reinterpret_cast<const double2 *>(pv + s);
-                const double2 r2 = vel[0], r3 = vel[1]; // (vx,vy) (vz, -)
-                const float mass = __int_as_float((int)(__double_as_longlong(r1.y) & 0xffffffffLL));
-                const double hx = d_hat_in(d0);
-                const float x0 = (float)hx;
-                const float x1 = (float)d_hat_up(d0 + 0.5);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (!pass[r]) continue;
-                    const double e1 = d1[r % RY], e2 = d2[r / RY];
-                    const double hy = d_hat_in(e1), hz = d_hat_in(e2);
-                    const double wgt = hx * hy * hz;
-                    if (fw[r] > 0 && wgt > 0) {
-                        const double add = (double)0.f + wgt * (double)mass / denom[r];
-                        dens[r] = (float)((double)dens[r] + add);
-                    }
-                    const float y0 = (float)hy, z0 = (float)hz;
-                    const float y1 = (float)d_hat_up(e1 + 0.5), z1 = (float)d_hat_up(e2 + 0.5);
-                    const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
-                    if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
-                        ws0[r] = ws0[r] + w0; ws1[r] = ws1[r] + w1; ws2[r] = ws2[r] + w2;
-                        a0[r] = a0[r] + w0 * r2.x; a1[r] = a1[r] + w1 * r2.y; a2[r] = a2[r] + w2 * r3.x;
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (!live[r]) continue;
-        const long long c = d_lid(g, i, j0 + r % RY, k0 + r / RY);
-        u[c] = a0[r] / ws0[r];
-        v[c] = a1[r] / ws1[r];
-        w[c] = a2[r] / ws2[r];
-        active[c] = 1;
-        float dn = dens[r];
-        if (0 < fw[r] && fw[r] < 6) dn = dn > da.rest ? dn : da.rest;
-        da.density[c] = dn;
-        if ((double)dn > 1.5 * (double)da.rest) atomicAdd(da.n_over, 1);
-    }
-}
-
 static int ensure_records(flip_ctx *ctx) {
     if (ctx->prec_valid || ctx->n == 0) return 0;
-    ParticlePtrs ps;
-    for (int q = 0; q < 6; ++q) ps.a[q] = ctx->p[ctx->cur][q];
-    ps.mass = ctx->mass[ctx->cur];
-    ps.pid = ctx->pid[ctx->cur];
-    k_pack_records<<<flip_grid_blocks(ctx->n), FLIP_BLOCK, 0, ctx->stream>>>(ctx->n, ps, packed_pos(ctx), packed_vel(ctx));
+    k_pack_records<<<flip_grid_blocks(ctx->n), FLIP_BLOCK, 0, ctx->stream>>>(ctx->n, ctx->cell_start + ctx->B, particle_ptrs(ctx, ctx->cur),
+                                                                            ctx->sub_slot, packed_pos(ctx), packed_vel(ctx), ctx->pcell);
     FLIP_LAUNCH_CHECK();
     ctx->prec_valid = true;
     return 0;
@@ -519,26 +540,9 @@ extern "C" int flip_p2g(flip_ctx *ctx) {
     DensityArgs da{ ctx->phi_fluid, ctx->density, ctx->d_counts + 2, ctx->g.phi_fluid_bg, ctx->g.rest_density,
                     pow((double)ctx->g.dx, 3) };
     FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
-    // cells per thread in y and z.  Measured at 256^3 (8 particles per cell): 1x1 2.95 ms, 2x1 2.13, 3x1 2.07, 4x1 2.20,
-    // 1x2 2.13, 2x2 2.67, 3x2 3.66 (registers).  FLIP_P2G_BLOCK=yz selects 21, 31, 12 or 11 (the one-cell kernel) for tuning.
-    static const int shape = [] { const char *e = getenv("FLIP_P2G_BLOCK"); const int v = e ? atoi(e) : 31; return v; }();
-    const int ry = shape / 10, rz = shape % 10;
-#define FLIP_P2G_LAUNCH(RY, RZ)                                                                                              \
-    do {                                                                                                                     \
-        const int nyb = (ctx->g.ny + RY - 1) / RY, nzb = (ctx->g.nz + RZ - 1) / RZ;                                          \
-        const long long threads = (long long)ctx->g.nx * nyb * nzb;                                                          \
-        k_p2g_block<RY, RZ><<<flip_grid_blocks(threads), FLIP_BLOCK, 0, ctx->stream>>>(                                      \
-            flip_dims(ctx), nyb, nzb, ctx->cell_start, ctx->band, packed_pos(ctx), packed_vel(ctx), ctx->vel[1][0], ctx->vel[1][1], \
-            ctx->vel[1][2], ctx->active, da);                                                                                \
-    } while (0)
-    if (ry == 2 && rz == 1) FLIP_P2G_LAUNCH(2, 1);
-    else if (ry == 3 && rz == 1) FLIP_P2G_LAUNCH(3, 1);
-    else if (ry == 1 && rz == 2) FLIP_P2G_LAUNCH(1, 2);
-    else
-        k_p2g<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->cell_start, ctx->band, packed_pos(ctx),
-                                                                       packed_vel(ctx), ctx->vel[1][0], ctx->vel[1][1], ctx->vel[1][2],
-                                                                       ctx->active, da);
-#undef FLIP_P2G_LAUNCH
+    k_gather<true><<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->sub_start, ctx->band, packed_pos(ctx),
+                                                                            packed_vel(ctx), ctx->vel[1][0], ctx->vel[1][1], ctx->vel[1][2],
+                                                                            ctx->active, da);
     FLIP_LAUNCH_CHECK();
     ctx->density_valid = true;
     for (int a = 0; a < 3; ++a) std::swap(ctx->vel[0][a], ctx->vel[1][a]);
@@ -669,14 +673,6 @@ __global__ void k_unpack_recv(long long m, const flip_prec *__restrict__ in, Par
     dst.a[0][o] = r.x; dst.a[1][o] = r.y; dst.a[2][o] = r.z; dst.a[3][o] = r.vx; dst.a[4][o] = r.vy; dst.a[5][o] = r.vz;
     dst.mass[o] = r.mass;
     dst.pid[o] = (int32_t)o;
-}
-
-static ParticlePtrs particle_ptrs(flip_ctx *ctx, int buffer) {
-    ParticlePtrs ps;
-    for (int q = 0; q < 6; ++q) ps.a[q] = ctx->p[buffer][q];
-    ps.mass = ctx->mass[buffer];
-    ps.pid = ctx->pid[buffer];
-    return ps;
 }
 
 extern "C" int flip_particles_pack(flip_ctx *ctx, int32_t plane_lo, int32_t plane_hi, void *device_out, int64_t capacity,
@@ -877,7 +873,7 @@ extern "C" int flip_fluid_levelset_from_particles(flip_ctx *ctx, float radius_wo
     constexpr int R = 3; // cells per thread: 1: 3.9 ms at 256^3, 2: 2.6, 3 and 4: 2.4
     const int nyb = (ctx->g.ny + R - 1) / R;
     k_fluid_levelset<R><<<flip_grid_blocks((long long)ctx->g.nx * nyb * ctx->g.nz), FLIP_BLOCK, 0, ctx->stream>>>(
-        g, nyb, ctx->g.dx, radius, (double)half_width_voxels, reach, ctx->cell_start, packed_pos(ctx), ctx->tmp_u8, ctx->phi_solid,
+        g, nyb, ctx->g.dx, radius, (double)half_width_voxels, reach, ctx->cell_start, ctx->pcell, ctx->tmp_u8, ctx->phi_solid,
         ctx->phi_fluid);
     FLIP_LAUNCH_CHECK();
     ctx->density_valid = false;
@@ -968,50 +964,7 @@ extern "C" int flip_advect_particles(flip_ctx *ctx, float dt) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Density (src/FluidSimulator.cpp:625-652, src/Functors.cpp:216-266).
-
-__global__ void k_density(GridDims g, float phi_bg, float rest, double vs3, const int32_t *__restrict__ cell_start,
-                          const uint8_t *__restrict__ band, const float *__restrict__ phi, const flip_ppos *__restrict__ prec,
-                          float *__restrict__ density, int32_t *__restrict__ n_over) {
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.B) return;
-    if (!(band[c] & 2)) { density[c] = 0.f; return; }
-    int i, j, k;
-    d_ijk(g, c, i, j, k);
-    const float pc = phi[c];
-    const float fw = d_frac2(d_getf(g, phi, i - 1, j, k, phi_bg), pc) + d_frac2(d_getf(g, phi, i, j - 1, k, phi_bg), pc)
-                     + d_frac2(d_getf(g, phi, i, j, k - 1, phi_bg), pc) + d_frac2(d_getf(g, phi, i + 1, j, k, phi_bg), pc)
-                     + d_frac2(d_getf(g, phi, i, j + 1, k, phi_bg), pc) + d_frac2(d_getf(g, phi, i, j, k + 1, phi_bg), pc);
-    float dens = 0.f;
-    const double denom = (double)(fw / 6) * vs3;
-    const double cx = (double)(g.ox + i), cy = (double)(g.oy + j), cz = (double)(g.oz + k);
-    const int i0 = i > 0 ? i - 1 : 0, i1 = i < g.nx - 1 ? i + 1 : g.nx - 1;
-    if (fw > 0) {
-        for (int kk = k - 1; kk <= k + 1; ++kk) {
-            if (kk < 0 || kk >= g.nz) continue;
-            for (int jj = j - 1; jj <= j + 1; ++jj) {
-                if (jj < 0 || jj >= g.ny) continue;
-                const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
-                const int32_t s0 = cell_start[row + i0], s1 = cell_start[row + i1 + 1];
-                for (int32_t s = s0; s < s1; ++s) {
-                    const double2 *rec = reinterpret_cast<const double2 *>(prec + s);
-                    const double2 r0 = rec[0];
-                    const double rz = prec[s].z;
-                    const double d0 = r0.x - cx, d1 = r0.y - cy, d2 = rz - cz;
-                    if (fabs(d0) > 1. || fabs(d1) > 1. || fabs(d2) > 1.) continue;
-                    const double wgt = d_hat_in(d0) * d_hat_in(d1) * d_hat_in(d2);
-                    if (wgt > 0) {
-                        const double add = (double)0.f + wgt * (double)prec[s].mass / denom;
-                        dens = (float)((double)dens + add);
-                    }
-                }
-            }
-        }
-    }
-    if (0 < fw && fw < 6) dens = dens > rest ? dens : rest;
-    density[c] = dens;
-    if ((double)dens > 1.5 * (double)rest) atomicAdd(n_over, 1);
-}
+// Density alone (src/FluidSimulator.cpp:625-652, src/Functors.cpp:216-266): the density-only form of k_gather.
 
 extern "C" int flip_density(flip_ctx *ctx, int64_t *n_overdense) {
     FLIP_REQUIRE(ctx, "null context");
@@ -1019,11 +972,11 @@ extern "C" int flip_density(flip_ctx *ctx, int64_t *n_overdense) {
     FLIP_CHECK(hipSetDevice(ctx->device));
     if (!ctx->density_valid) {
         if (int rc = ensure_records(ctx)) return rc;
-        const double vs3 = pow((double)ctx->g.dx, 3);
+        DensityArgs da{ ctx->phi_fluid, ctx->density, ctx->d_counts + 2, ctx->g.phi_fluid_bg, ctx->g.rest_density,
+                        pow((double)ctx->g.dx, 3) };
         FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
-        k_density<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->g.phi_fluid_bg, ctx->g.rest_density,
-                                                                           vs3, ctx->cell_start, ctx->band, ctx->phi_fluid,
-                                                                           packed_pos(ctx), ctx->density, ctx->d_counts + 2);
+        k_gather<false><<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->sub_start, ctx->band, packed_pos(ctx),
+                                                                                 packed_vel(ctx), nullptr, nullptr, nullptr, nullptr, da);
         FLIP_LAUNCH_CHECK();
         ctx->density_valid = true;
     }

@@ -236,20 +236,63 @@ ORC_EXPORT void orc_particle_mask(const orc_grid *g, const int32_t *cell_start, 
             }
 }
 
+/* Visit order of the particles one cell gathers.  The reference walks whatever list OpenVDB's ParticleAtlas   */
+/* hands back for the query box (src/Functors.cpp:21-26): an order internal to OpenVDB and to the TBB schedule, */
+/* so any fixed order restates it equally well (parity unpinned).  The order used here and by the GPU library:  */
+/* neighbour grid rows (kk, jj) ascending; inside a row by half cell -- z half, then y half, then position      */
+/* along x in half cells (2*ii + x half) -- and by upload index inside one half cell.  "Upper half" of a cell    */
+/* n is decided by the expression the gather of cell n+1 evaluates for the lower edge of its query box,        */
+/* pos - (n+1) >= -1, so that a half cell is either wholly inside or wholly outside that box.                   */
+static inline int upper_half(double p, int n_index) { return (p - (double)(n_index + 1)) >= -1.0 ? 1 : 0; }
+
+typedef struct { int32_t key; int32_t p; } orc_cand;
+static int cand_cmp(const void *a, const void *b) {
+    const orc_cand *x = (const orc_cand *)a, *y = (const orc_cand *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->p < y->p ? -1 : (x->p > y->p ? 1 : 0);
+}
+/* The particles of cells (i-1..i+1, jj, kk) in visit order.  *buf grows as needed. */
+static int32_t row_candidates(const orc_grid *g, const double *pos, const int32_t *cell_start, const int32_t *perm,
+                              int i, int jj, int kk, orc_cand **buf, int32_t *cap) {
+    int32_t m = 0;
+    for (int ii = i - 1; ii <= i + 1; ++ii) {
+        if (!inside(g, ii, jj, kk)) continue;
+        const int64_t nb = lid(g, ii, jj, kk);
+        for (int32_t s = cell_start[nb]; s < cell_start[nb + 1]; ++s) {
+            const int32_t p = perm[s];
+            if (m == *cap) {
+                *cap = *cap ? 2 * *cap : 64;
+                *buf = (orc_cand *)realloc(*buf, (size_t)*cap * sizeof(orc_cand));
+            }
+            const int hx = upper_half(pos[3 * (int64_t)p], g->ox + ii);
+            const int hy = upper_half(pos[3 * (int64_t)p + 1], g->oy + jj);
+            const int hz = upper_half(pos[3 * (int64_t)p + 2], g->oz + kk);
+            (*buf)[m].key = (hz * 2 + hy) * (2 * g->nx) + 2 * ii + hx;
+            (*buf)[m].p = p;
+            ++m;
+        }
+    }
+    if (m > 1) qsort(*buf, (size_t)m, sizeof(orc_cand), cand_cmp);
+    return m;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* P2G gather: src/FluidSimulator.cpp:71-118 + src/Functors.cpp:10-45.                  */
 /* For every cell of the band (particle cells dilated 2) visit the particles with        */
 /* |pos - cell| <= 1 per axis (the atlas query box of Functors.cpp:21-24 with zero       */
 /* radii), accumulate weight and weight*velocity in double starting from the grids'      */
 /* backgrounds (weight: float 10e-37 widened; velocity: 0), then divide component-wise   */
-/* (FluidSimulator.cpp:108).  Visit order: neighbour cells in ascending linear id, the   */
-/* particles of a cell in stable sorted order.                                          */
+/* (FluidSimulator.cpp:108).  Visit order: see row_candidates.                            */
 ORC_EXPORT void orc_p2g(const orc_grid *g, int64_t n, const double *pos, const double *vel,
                         const int32_t *cell_start, const int32_t *perm, const uint8_t *band,
                         double *u, double *v, double *w) {
     (void)n;
     const float epsilon = 10e-37f; /* FluidSimulator.cpp:32 */
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel
+    {
+    orc_cand *buf = NULL;
+    int32_t cap = 0;
+#pragma omp for schedule(dynamic, 1)
     for (int k = 0; k < g->nz; ++k)
         for (int j = 0; j < g->ny; ++j)
             for (int i = 0; i < g->nx; ++i) {
@@ -260,11 +303,10 @@ ORC_EXPORT void orc_p2g(const orc_grid *g, int64_t n, const double *pos, const d
                 const double cx = (double)(g->ox + i), cy = (double)(g->oy + j), cz = (double)(g->oz + k);
                 for (int kk = k - 1; kk <= k + 1; ++kk)
                     for (int jj = j - 1; jj <= j + 1; ++jj)
-                        for (int ii = i - 1; ii <= i + 1; ++ii) {
-                            if (!inside(g, ii, jj, kk)) continue;
-                            const int64_t nb = lid(g, ii, jj, kk);
-                            for (int32_t s = cell_start[nb]; s < cell_start[nb + 1]; ++s) {
-                                const int64_t p = perm[s];
+                        {
+                            const int32_t m = row_candidates(g, pos, cell_start, perm, i, jj, kk, &buf, &cap);
+                            for (int32_t s = 0; s < m; ++s) {
+                                const int64_t p = buf[s].p;
                                 double d[3] = { pos[3 * p] - cx, pos[3 * p + 1] - cy, pos[3 * p + 2] - cz };
                                 if (d[0] < -1. || d[0] > 1. || d[1] < -1. || d[1] > 1. || d[2] < -1. || d[2] > 1.)
                                     continue; /* outside the atlas query box */
@@ -282,6 +324,8 @@ ORC_EXPORT void orc_p2g(const orc_grid *g, int64_t n, const double *pos, const d
                 v[c] = vs[1] / ws[1];
                 w[c] = vs[2] / ws[2];
             }
+    free(buf);
+    }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -461,7 +505,11 @@ ORC_EXPORT int64_t orc_density(const orc_grid *g, int64_t n, const double *pos, 
     const float bg = g->phi_fluid_bg;
     const double vs3 = pow((double)g->dx, 3);
     int64_t n_over = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : n_over)
+#pragma omp parallel reduction(+ : n_over)
+    {
+    orc_cand *buf = NULL;
+    int32_t cap = 0;
+#pragma omp for schedule(dynamic, 1)
     for (int k = 0; k < g->nz; ++k)
         for (int j = 0; j < g->ny; ++j)
             for (int i = 0; i < g->nx; ++i) {
@@ -478,11 +526,10 @@ ORC_EXPORT int64_t orc_density(const orc_grid *g, int64_t n, const double *pos, 
                 const double cx = (double)(g->ox + i), cy = (double)(g->oy + j), cz = (double)(g->oz + k);
                 for (int kk = k - 1; kk <= k + 1; ++kk)
                     for (int jj = j - 1; jj <= j + 1; ++jj)
-                        for (int ii = i - 1; ii <= i + 1; ++ii) {
-                            if (!inside(g, ii, jj, kk)) continue;
-                            const int64_t nb = lid(g, ii, jj, kk);
-                            for (int32_t s = cell_start[nb]; s < cell_start[nb + 1]; ++s) {
-                                const int64_t p = perm[s];
+                        {
+                            const int32_t m = row_candidates(g, pos, cell_start, perm, i, jj, kk, &buf, &cap);
+                            for (int32_t s = 0; s < m; ++s) {
+                                const int64_t p = buf[s].p;
                                 double d[3] = { pos[3 * p] - cx, pos[3 * p + 1] - cy, pos[3 * p + 2] - cz };
                                 if (d[0] < -1. || d[0] > 1. || d[1] < -1. || d[1] > 1. || d[2] < -1. || d[2] > 1.)
                                     continue;
@@ -499,6 +546,8 @@ ORC_EXPORT int64_t orc_density(const orc_grid *g, int64_t n, const double *pos, 
                 density[c] = dens;
                 if ((double)dens > 1.5 * (double)rest_density) ++n_over;
             }
+    free(buf);
+    }
     return n_over;
 }
 
