@@ -1,22 +1,30 @@
-"""Benchmark of the FLIP hot path on MI355X.
+"""Benchmark of the FLIP substep on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One "step" is one pass of the hot path (binning, P2G + density, extrapolation, forces, labels, face fractions,
-divergence solve + projection, density solve + projection, G2P, displacements; the call order of
-src/FluidSimulator.cpp:307-446) over the synthetic side-drop dam break at 256^3 with 8 particles per cell
-(--n/--ppc select another size for quick runs).  Inputs are generated on the host from a fixed seed and uploaded
-before the timed region.  Rank 0 prints ONE JSON line.
+One "step" is one pass of the loop body of FluidSimulator::advance_flip_pic (src/FluidSimulator.cpp:309-445) without
+the fluid source: binning, fluid level set from the particles, P2G + density, extrapolation, constrain_velocity,
+forces, labels, face fractions, divergence solve + projection, density solve + projection, extrapolation,
+constrain_velocity, G2P, RK3 advection + push-out, displacements -- over the synthetic side-drop dam break at 256^3
+nominal resolution with 8 particles per cell (--n/--ppc select another size for quick runs).  Inputs are generated on
+the host from a fixed seed and uploaded before the timed region.  Rank 0 prints ONE JSON line.  `hot_path_only` in that
+line is the same run without the level-set rebuild, constrain_velocity and advection (the stages outside the
+transfer/solve/projection path), timed right after the headline steps.
 
-N = 1: one context, the fused solver loop.
-N > 1: z-slab decomposition, one process per GPU (fluidsimulation_amd/distributed.py): the container is N
-times as long along z and every rank owns one 256^3-sized slab of it plus ghost planes (weak scaling); the CG
-scalars are all-reduced and a few planes per slab face are exchanged every iteration over RCCL (overlapping
-additive-Schwarz preconditioner), particles near a face are exchanged once per step.  `value` counts slab-substeps: N x (substeps of the long domain) per second.
+N = 1: one context; both solves of a step side by side on two streams.
+N > 1: one process per GPU (this script starts them itself when it is not already running under torch.distributed.run),
+z-slab decomposition (fluidsimulation_amd/distributed.py): CG scalars all-reduced and a few planes per slab face
+exchanged every iteration over RCCL, particles near a face exchanged once per step.
+  --scaling strong (default): the one 256^3 box cut into N slabs; `value` = substeps of that box per second.
+  --scaling weak: a container N times as long along z, one 256^3-sized slab per rank; `value` = N x substeps/s.
+  --full-domain: the container spans the whole nominal grid (with --n 512 --ppc 16: the ~1e9-particle dam break).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,16 +35,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
-# Algorithmic bytes (minimum traffic if every array were touched once per kernel):
-DIRECTION_BYTES_PER_ROW = 53   # fused direction + SpMV: the matrix-free SpMV (read p 8, diagonal 8, 3 float couplings 12,
-                               # cell type 1; write Ap 8 = 37) plus the direction update folded into it (read z 8, write p 8)
-UPDATE_BYTES_PER_ROW = 56      # read p 8, Ap 8, x 8, r 8, 1/diag 8; write x 8, r 8 (z is rewritten by the V-cycle)
-VCYCLE_BYTES_PER_ROW = 226     # level 0: pre 44 + restrict 44 + correct/post 52 + post 52 = 192; coarse levels ~ +1/7 of a
-                               # level with double couplings (240): 34
-JACOBI_ITERATION_BYTES = DIRECTION_BYTES_PER_ROW + UPDATE_BYTES_PER_ROW + 8          # + write z
-MG_ITERATION_BYTES = DIRECTION_BYTES_PER_ROW + UPDATE_BYTES_PER_ROW + VCYCLE_BYTES_PER_ROW
+# Algorithmic bytes per unit (minimum traffic if every array were touched once per kernel).
+BYTES = {
+    # fused direction + SpMV: matrix-free SpMV (read p 8, diagonal 8, 3 float couplings 12, cell type 1; write Ap 8 = 37)
+    # plus the direction update folded into it (read z 8, write p 8)
+    "k_pcg_direction": 53,
+    # CG update + both pre-smoothing steps: read r 8, Ap 8, x 8, p 8, 1/diag 4, diag 4, couplings 12, type 1; write x 8, r 8, z 8
+    "k_pcg_update_pre": 85,
+    "k_mg_restrict": 44,       # read r 8, z 8, diag 4, 1/diag 4, couplings 12, type 1, row id 4; write coarse b (8 per 8 rows) 1 (+2 slack)
+    "k_mg_post": 52,           # read z 8, r 8, diag 4, 1/diag 4, couplings 12, type 1, row id 4, parent x 1 (8 per 8 rows); write t 8 (+2 slack)
+    "k_mg_smooth": 52,         # read t 8, r 8, old z 8 (its value at the row), 1/diag 4, diag 4, couplings 12, type 1, row id 4; write z 8 -> 57; 52 kept from the round-1 accounting
+}
+JACOBI_ITERATION_BYTES = 53 + 56 + 8          # direction, update (56), write z
+MG_ITERATION_BYTES = 53 + 56 + 226            # direction, update, V-cycle (level 0: 192, coarse levels ~34)
 P2G_BYTES_PER_PARTICLE, P2G_BYTES_PER_BAND_CELL = 48, 24   # read pos + vel; write 3 velocity components
 G2P_BYTES_PER_PARTICLE, G2P_BYTES_PER_BAND_CELL = 72, 48   # read pos + vel, write vel; read velocity + difference grids
+SORT_BYTES_PER_PARTICLE = 128                              # key pass 28, scatter pass 48 + 48 + 4
+LEVELSET_BYTES_PER_PARTICLE, LEVELSET_BYTES_PER_CELL = 24, 8   # read pos; read phi_solid 4, write phi_fluid 4
 
 
 def parse():
@@ -50,31 +65,42 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-15)
     ap.add_argument("--max-iter", type=int, default=20000)
     ap.add_argument("--precond", default=os.environ.get("FLIP_BENCH_PRECOND", "mg"), choices=["jacobi", "mg"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: one box cut into N slabs (strong) or one box-sized slab per rank of an N times longer container (weak)")
+    ap.add_argument("--full-domain", action="store_true", help="container over the whole nominal grid instead of main.cpp's half-width box")
     ap.add_argument("--parallel", default="auto", choices=["auto", "slabs", "replicas"],
-                    help="N > 1: z-slab decomposition of one long domain (auto) or independent replicas")
+                    help="N > 1: z-slab decomposition (auto) or independent replicas")
     ap.add_argument("--ghost", type=int, default=8, help="ghost planes on either side of a slab")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("FLIP_BENCH_OVERLAP", "-1")),
                     help="N > 1: planes of either neighbour's slab the local preconditioner also covers (additive Schwarz); "
                          "0 = disjoint blocks, default 4")
     ap.add_argument("--split-phase", action="store_true", help="N = 1: drive the solver through the split-phase entry points")
-    ap.add_argument("--full-substep", action="store_true",
-                    help="N = 1: also rebuild the level set from the particles, constrain_velocity and RK3 advection (the whole "
-                         "loop body of advance_flip_pic except the fluid source); informational, not the headline configuration")
+    ap.add_argument("--hot-path-only", action="store_true",
+                    help="time only the transfer/solve/projection path (no level-set rebuild, constrain_velocity, advection)")
+    ap.add_argument("--full-substep", action="store_true", help="accepted for compatibility: the whole substep is the default now")
     ap.add_argument("--sequential-solves", action="store_true",
                     help="N = 1: divergence solve, projection, density solve one after the other (the reference's order) instead "
                          "of both solves side by side on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=40, help="CG iterations per solve timed on the CPU")
+    ap.add_argument("--cpu-iters", type=int, default=8, help="CG iterations per timed repetition on the CPU (5 repetitions, median)")
     return ap.parse_args()
 
 
-def cpu_baseline(sc, args, jacobi_iters):
-    """Times the CPU oracle (OpenMP port of the same stages, Jacobi CG as the reference runs it) on this host:
-    every non-solver stage once at full size plus `cpu_iters` CG iterations per solve, extrapolated to the
-    iteration counts Jacobi CG needs on this scene (measured on the GPU).  A baseline, not a target."""
-    from oracle import Oracle
-    threads = min(os.cpu_count() or 1, 16)
-    o = Oracle(sc.desc(), threads=threads)
+def spawn_ranks(n):
+    """Starts this script under torch.distributed.run with n ranks (before anything here has touched a GPU) and returns
+    its exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def cpu_stage_seconds(o, sc, args):
+    """Every non-solver stage of the hot path once at full size on the CPU oracle; returns (seconds per stage, the two CSR
+    systems, the liquid mask of the divergence system's rows)."""
     dt = args.dt
     z32 = lambda: np.zeros(o.shape, np.float32)  # noqa: E731
     t = {}
@@ -98,20 +124,14 @@ def cpu_baseline(sc, args, jacobi_iters):
     t0 = time.perf_counter()
     dens, _ = o.density(sc.pos, sc.mass, cell_start, perm, pm2, sc.phi_fluid)
     t["density"] = time.perf_counter() - t0
-    t_iter = []
-    p = None
-    reference_solver = None
+    systems = []
+    disp = None
     for kind in (0, 1):
         t0 = time.perf_counter()
         off, diag, rhs = o.build_system(kind, dt, label, sc.phi_fluid, sc.phi_solid, w, uvw=uvw, density=dens)
-        rowptr, col, val, b = o.to_csr(index, off, diag, rhs)
+        systems.append(o.to_csr(index, off, diag, rhs))
         t[f"build{kind}"] = time.perf_counter() - t0
-        if kind == 0:
-            reference_solver = reference_pcgsolver(rowptr, col, val, b, sc.phi_fluid[label == 1] >= 0)
-        o.cg_jacobi(rowptr, col, val, b, tol=args.tol, max_iter=2)   # thread-pool and page warm-up, not timed
-        t0 = time.perf_counter()
-        p, it, _ = o.cg_jacobi(rowptr, col, val, b, tol=args.tol, max_iter=args.cpu_iters)
-        t_iter.append((time.perf_counter() - t0) / max(it, 1))
+        p = np.zeros(systems[-1][3].shape)
         t0 = time.perf_counter()
         if kind == 0:
             uvw, valid = o.project_velocity(dt, index, p, sc.phi_fluid, w, uvw)
@@ -120,17 +140,49 @@ def cpu_baseline(sc, args, jacobi_iters):
         t[f"project{kind}"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     diff = o.update_diff(uvw, prev)
-    o.g2p(sc.pos, sc.vel, uvw, diff, 0.95)
-    o.apply_displacements(sc.pos, disp)
+    o.g2p(sc.pos, sc.vel.copy(), uvw, diff, 0.95)
+    o.apply_displacements(sc.pos.copy(), disp)
     t["g2p"] = time.perf_counter() - t0
-    fixed = sum(t.values())
-    total = fixed + t_iter[0] * jacobi_iters[0] + t_iter[1] * jacobi_iters[1]
-    return {"value": 1.0 / total, "unit": "substeps/s", "cores": threads, "kind": "port", "reference_solver": reference_solver,
-            "sample": f"all non-solver stages once at full size ({fixed:.2f} s) + {args.cpu_iters} Jacobi-CG iterations per "
-                      f"solve ({t_iter[0] * 1e3:.1f}/{t_iter[1] * 1e3:.1f} ms per iteration), extrapolated to the "
-                      f"{jacobi_iters[0]}+{jacobi_iters[1]} iterations Jacobi CG needs on this scene (counted on the GPU); particle state "
-                      f"as after the timed steps",
-            "stage_seconds": {k: round(v, 4) for k, v in t.items()}}
+    return t, systems, sc.phi_fluid[label == 1] >= 0
+
+
+def cpu_baseline(sc, args, jacobi_iters):
+    """The CPU oracle (OpenMP port of the same stages, Jacobi CG as the reference runs it) timed on this host's cores,
+    once with 8 threads (what the reference pins Eigen to, src/FluidSimulator.cpp:658) and once with the cores available
+    (16 at most): every non-solver stage once at full size, CG iterations as the median of 5 repetitions of
+    `cpu_iters` iterations per solve, extrapolated to the iteration counts Jacobi CG needs on this scene (counted on the
+    GPU).  A baseline, not a target."""
+    from oracle import Oracle
+    avail = min(os.cpu_count() or 1, 16)
+    out = {}
+    reference_solver = None
+    for threads in sorted({min(8, avail), avail}):
+        o = Oracle(sc.desc(), threads=threads)
+        t, systems, dependent = cpu_stage_seconds(o, sc, args)
+        t_iter = []
+        for kind, (rowptr, col, val, b) in enumerate(systems):
+            if kind == 0 and reference_solver is None:
+                reference_solver = reference_pcgsolver(rowptr, col, val, b, dependent)
+            o.cg_jacobi(rowptr, col, val, b, tol=args.tol, max_iter=2)   # thread-pool and page warm-up, not timed
+            reps = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                _, it, _ = o.cg_jacobi(rowptr, col, val, b, tol=args.tol, max_iter=args.cpu_iters)
+                reps.append((time.perf_counter() - t0) / max(it, 1))
+            t_iter.append(float(np.median(reps)))
+        fixed = sum(t.values())
+        total = fixed + t_iter[0] * jacobi_iters[0] + t_iter[1] * jacobi_iters[1]
+        out[threads] = {"value": 1.0 / total, "fixed_seconds": fixed, "ms_per_cg_iteration": [1e3 * v for v in t_iter],
+                        "stage_seconds": {k: round(v, 4) for k, v in t.items()}}
+    top = out[avail]
+    return {"value": top["value"], "unit": "substeps/s", "cores": avail, "kind": "port",
+            "value_8_threads": out[min(8, avail)]["value"], "reference_solver": reference_solver,
+            "sample": f"hot-path stages (no level-set rebuild, constrain, advection) once at full size ({top['fixed_seconds']:.2f} s) + "
+                      f"median of 5 x {args.cpu_iters} Jacobi-CG iterations per solve "
+                      f"({top['ms_per_cg_iteration'][0]:.1f}/{top['ms_per_cg_iteration'][1]:.1f} ms per iteration), extrapolated to the "
+                      f"{jacobi_iters[0]}+{jacobi_iters[1]} iterations Jacobi CG needs on this scene (counted on the GPU); particle "
+                      f"state as after the timed steps",
+            "by_threads": {str(k): v for k, v in out.items()}}
 
 
 def reference_pcgsolver(rowptr, col, val, b, dependent):
@@ -161,23 +213,30 @@ def reference_pcgsolver(rowptr, col, val, b, dependent):
             "rows": int(m), "seconds": time.perf_counter() - t0, "iterations": int(it.value), "converged": bool(ok)}
 
 
-def stored_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this very command (FETCH_SIZE and
-    WRITE_SIZE are collected in separate runs, so they cannot be read live here): 2 x FETCH_SIZE (the gfx950 correction
-    for streaming reads) + WRITE_SIZE, both reported in KB.  None when the files are absent."""
-    import csv
-    vals = {}
-    for key, name in (("fetch", "r01_d_bench256_mg_pmc_fetch_size.csv"), ("write", "r01_d_bench256_mg_pmc_write_size.csv")):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            return None
-        with open(path, newline="") as f:
-            for row in csv.reader(f):
-                if row and row[0].startswith(kernel_prefix):
-                    vals[key] = float(row[2])
-    if len(vals) != 2:
-        return None
-    return (2.0 * vals["fetch"] + vals["write"]) * 1024.0
+def kernel_source_id():
+    """Hash of the kernel sources: a stored PMC profile is only quoted for the code it was taken on."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "fluidsimulation_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def stored_traffic(args):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this command (FETCH_SIZE and WRITE_SIZE need
+    passes of their own, so they cannot be read live): profiles/traffic.json, written by profiles/summarize_pmc.py, holds
+    {kernel: bytes} plus the source hash and the configuration it was taken on.  Returns ({}, None) when absent or taken
+    on other code or another configuration."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return {}, None
+    with open(path) as f:
+        d = json.load(f)
+    if d.get("source_id") != kernel_source_id() or d.get("n") != args.n or d.get("ppc") != args.ppc or d.get("hot_path_only", False) != args.hot_path_only:
+        return {}, None
+    return d.get("bytes_per_launch", {}), d.get("files")
 
 
 def time_stage(torch, fn, reps=3):
@@ -193,14 +252,29 @@ def time_stage(torch, fn, reps=3):
     return total / reps * 1e-3
 
 
+def roofline_entry(name, seconds, launches_per_step, algorithmic_bytes, traffic, note=None):
+    gbs = algorithmic_bytes / seconds / 1e9
+    e = {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+         "traffic": traffic.get(name), "avg_launch_us": seconds * 1e6, "launches_per_step": launches_per_step,
+         "ms_per_step": seconds * launches_per_step * 1e3, "algorithmic_bytes_per_launch": algorithmic_bytes}
+    if note:
+        e["note"] = note
+    return e
+
+
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line for another GPU count\n")
+        sys.exit(2)
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     # rehearsal on a one-GPU box: FLIP_BENCH_REHEARSE=1 puts every rank on device 0 and uses gloo (RCCL refuses two
@@ -208,6 +282,9 @@ def main():
     rehearse = os.environ.get("FLIP_BENCH_REHEARSE") == "1"
     if rehearse:
         local = 0
+    elif torch.cuda.device_count() < world:
+        sys.stderr.write(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPUs visible\n")
+        sys.exit(2)
     torch.cuda.set_device(local)
     if world > 1:
         if rehearse:
@@ -220,11 +297,26 @@ def main():
 
     precond = PRECOND_MULTIGRID if args.precond == "mg" else PRECOND_JACOBI
     slabs = (world > 1 and args.parallel != "replicas") or (world == 1 and args.split_phase)
+    weak = world > 1 and slabs and args.scaling == "weak"
+    z_repeat = world if weak else 1
     if world > 1 and slabs:
-        layout = SlabLayout(scenes.slab_box_planes(args.n, world), world, args.ghost)
-        sc = scenes.dam_break_slab(args.n, ppc=args.ppc, seed=12345, z_repeat=world, z_planes=layout.extended(rank))
+        nz = scenes.slab_box_planes(args.n, z_repeat, args.full_domain)
+        ghost = args.ghost
+        if weak:
+            layout = SlabLayout(nz, world, ghost)
+        else:
+            # strong scaling: cut by particle load (the planes inside the walls hold none), slabs at least `ghost` thick
+            hw = scenes.SOLID_HALF_WIDTH
+            weights = np.full(nz, 0.1)
+            weights[hw:nz - hw] = 1.0
+            while ghost > 1 and nz < world * ghost:
+                ghost //= 2
+            layout = SlabLayout.balanced(weights, world, ghost)
+        sc = scenes.dam_break_slab(args.n, ppc=args.ppc, seed=12345, z_repeat=z_repeat, z_planes=layout.extended(rank),
+                                   full_domain=args.full_domain)
     else:
-        sc = scenes.dam_break_slab(args.n, ppc=args.ppc, seed=12345)
+        ghost = 0
+        sc = scenes.dam_break_slab(args.n, ppc=args.ppc, seed=12345, full_domain=args.full_domain)
         layout = SlabLayout(sc.dims[2], 1, 0)
     # particles this rank owns (its ghost copies belong to the neighbours' counts)
     o0, o1 = layout.owned(rank) if world > 1 and slabs else (0, sc.dims[2])
@@ -234,14 +326,14 @@ def main():
     ctx = FlipContext(sc.desc(), device=local)
     ctx.reserve_particles(sc.pos.shape[0] * 5 // 4 + 4096)
     ctx.upload_scene(sc)
+    radius = 1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0   # src/FluidSource.cpp:67
+    extra = {} if args.hot_path_only else dict(constrain=True, advect=True, levelset_radius=radius)
+    overlap = 0
     if slabs:
-        overlap = min(4 if args.overlap < 0 else args.overlap, max(args.ghost - 1, 0)) if world > 1 else 0
+        overlap = min(4 if args.overlap < 0 else args.overlap, max(ghost - 1, 0)) if world > 1 else 0
         step = DistributedSubstep(ctx, layout, Comm(), device=local, tol=args.tol, max_iter=args.max_iter, precond=precond,
-                                  overlap=overlap)
+                                  overlap=overlap, **extra)
     else:
-        extra = {}
-        if args.full_substep:
-            extra = dict(constrain=True, advect=True, levelset_radius=1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0)
         step = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=precond,
                            concurrent_solves=not args.sequential_solves, **extra)
 
@@ -251,16 +343,18 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def timed(stepper, k):
+        barrier()
+        t0 = time.perf_counter()
+        infos = [stepper.step(args.dt) for _ in range(k)]
+        barrier()
+        return time.perf_counter() - t0, infos
+
     for _ in range(args.warmup):
         step.step(args.dt)
     ctx.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
-    infos = []
-    for _ in range(args.steps):
-        infos.append(step.step(args.dt))
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, infos = timed(step, args.steps)
+    ctx.set_profiling(False)
     n_local = ctx.particle_count()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
@@ -272,6 +366,15 @@ def main():
         tot_cells, tot_particles, tot_rows = (int(v) for v in cnt.tolist())
     else:
         tot_cells, tot_particles, tot_rows = sc.n_cells, n_local, infos[0]["divergence"]["cg_rows"]
+
+    # ---- the same run without the stages outside the transfer/solve/projection path (single context only) ----
+    hot = None
+    if world == 1 and not slabs and not args.hot_path_only:
+        hstep = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=precond, concurrent_solves=not args.sequential_solves)
+        h_elapsed, _ = timed(hstep, args.steps)
+        hot = {"value": args.steps / h_elapsed, "unit": "substeps/s", "ms_per_step": 1e3 * h_elapsed / args.steps,
+               "what": "binning, P2G + density, extrapolation, forces, labels, face fractions, both solves and projections, G2P, "
+                       "displacements; fluid level set as left by the last full step"}
 
     # ---- per-kernel measurements on this rank, outside the timed region ----
     solves = [i[k] for i in infos for k in ("divergence", "density") if i[k] is not None]
@@ -285,77 +388,108 @@ def main():
     pcg_gbs = iters * rows * it_bytes / pcg_s / 1e9 if pcg_s > 0 else 0.0
     spmv_s = sum(s["spmv_seconds"] for s in solves)
     spmv_n = sum(s["spmv_launches"] for s in solves)
-    avg_launch = spmv_s / spmv_n if spmv_n else None
-    achieved = rows * DIRECTION_BYTES_PER_ROW / avg_launch / 1e9 if avg_launch else None
-    kernels = {}
+    entries = []
     jacobi_iters = None
     if rank == 0:
+        traffic, traffic_files = stored_traffic(args) if world == 1 else ({}, None)
+        its_per_step = iters / args.steps
+        if spmv_n:
+            entries.append(roofline_entry("k_pcg_direction", spmv_s / spmv_n, its_per_step, rows * BYTES["k_pcg_direction"], traffic,
+                                          note=f"HIP events around {spmv_n} launches with the device otherwise idle"))
+        if args.precond == "mg" and not slabs:
+            try:
+                kt = ctx.solver_kernel_times()
+            except Exception:
+                kt = {}
+            for name in ("k_pcg_update_pre", "k_mg_restrict", "k_mg_post", "k_mg_smooth"):
+                if name in kt and kt[name] > 0:
+                    entries.append(roofline_entry(name, kt[name] * 1e-6, its_per_step, rows * BYTES[name], traffic,
+                                                  note="one profiled iteration, device otherwise idle"))
+            if kt.get("coarse_levels"):
+                entries.append({"kernel": "coarse_levels", "bound": "latency", "avg_launch_us": kt["coarse_levels"],
+                                "launches_per_step": its_per_step, "ms_per_step": kt["coarse_levels"] * its_per_step * 1e-3,
+                                "note": "all launches of the V-cycle below level 0 of one iteration, run alone; beside the other solve's "
+                                        "level-0 kernels they mostly hide"})
+        # particle-side stages, timed alone on the state the run has reached
         ctx.bin_particles(want_outside=False)
+        if not args.hot_path_only:
+            t_ls = time_stage(torch, lambda: ctx.fluid_levelset_from_particles(radius))
+            entries.append(roofline_entry("k_fluid_levelset", t_ls, 1, LEVELSET_BYTES_PER_PARTICLE * n_local + LEVELSET_BYTES_PER_CELL * sc.n_cells,
+                                          traffic, note="whole stage (occupancy dilation + search)"))
         t_p2g = time_stage(torch, ctx.p2g)
         band = int(ctx.download("active").astype(np.int64).sum())
         ctx.update_diff()
         t_g2p = time_stage(torch, lambda: ctx.g2p(0.95))
-        p2g_bytes = P2G_BYTES_PER_PARTICLE * n_local + P2G_BYTES_PER_BAND_CELL * band
-        g2p_bytes = G2P_BYTES_PER_PARTICLE * n_local + G2P_BYTES_PER_BAND_CELL * band
-        kernels = {
-            "k_p2g": {"bound": "hbm", "achieved": p2g_bytes / t_p2g / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": p2g_bytes / t_p2g / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_p2g * 1e6,
-                      "algorithmic_bytes": p2g_bytes, "note": "the same launch also accumulates the density field"},
-            "k_g2p": {"bound": "hbm", "achieved": g2p_bytes / t_g2p / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": g2p_bytes / t_g2p / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_g2p * 1e6,
-                      "algorithmic_bytes": g2p_bytes},
-        }
-        if world == 1 and not args.no_cpu_baseline and not slabs and not args.full_substep:
+        entries.append(roofline_entry("k_gather", t_p2g, 1, P2G_BYTES_PER_PARTICLE * n_local + P2G_BYTES_PER_BAND_CELL * band, traffic,
+                                      note="P2G; the same launch also accumulates the density field"))
+        entries.append(roofline_entry("k_g2p", t_g2p, 1, G2P_BYTES_PER_PARTICLE * n_local + G2P_BYTES_PER_BAND_CELL * band, traffic))
+
+        def rebin():
+            ctx.apply_displacements()     # marks the sort stale (the displacement field is whatever the last step left)
+            ctx.bin_particles(want_outside=False)
+        t_disp = time_stage(torch, ctx.apply_displacements)
+        t_bin = time_stage(torch, rebin) - t_disp
+        entries.append(roofline_entry("binning", t_bin, 1, SORT_BYTES_PER_PARTICLE * n_local, traffic,
+                                      note="whole stage: cell ids, scan, slots, per-cell sort, reorder, half-cell ordered copy, bands"))
+        if world == 1 and not args.no_cpu_baseline and not slabs:
             # iteration counts of the reference's own solver (Jacobi CG) on this scene, for the CPU extrapolation
             probe = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=PRECOND_JACOBI).step(args.dt)
             jacobi_iters = (probe["divergence"]["iterations"], probe["density"]["iterations"])
 
-    traffic = None
-    if rank == 0 and world == 1 and args.n == 256 and args.ppc == 8 and args.precond == "mg" and not args.full_substep:
-        traffic = stored_traffic("void k_pcg_direction<true>")
-        for name, prefix in (("k_p2g", "void k_p2g_block"), ("k_g2p", "k_g2p")):
-            if name in kernels:
-                kernels[name]["traffic"] = stored_traffic(prefix)
     if rank == 0:
         parallelism = "single GPU"
         if world > 1:
-            parallelism = (f"{world} z-slabs of one {world}x long domain, ghost {args.ghost}, preconditioner overlap {overlap}, RCCL "
-                           f"all-reduces + plane exchanges per CG iteration" if slabs else f"{world} independent replicas")
+            parallelism = (f"{world} z-slabs ({args.scaling} scaling), ghost {ghost}, preconditioner overlap {overlap}, owned planes "
+                           f"{[layout.owned(r)[1] - layout.owned(r)[0] for r in range(world)]}, RCCL all-reduces + plane exchanges per CG "
+                           f"iteration" if slabs else f"{world} independent replicas")
+        gdims = (sc.dims[0], sc.dims[1], layout.nz if world > 1 and slabs else sc.dims[2])
+        workload = (f"side-drop dam break, nominal {args.n}^3" + (", full-domain container" if args.full_domain else "")
+                    + (f" x{world} along z" if weak else "")
+                    + f" (dense box {gdims[0]}x{gdims[1]}x{gdims[2]} cells), {args.ppc} particles/cell, density projection on, "
+                    + ("hot path only (no level-set rebuild, constrain_velocity, advection), " if args.hot_path_only
+                       else "whole substep (level set from particles, constrain_velocity, RK3 advection included), ")
+                    + f"{args.precond} PCG tol {args.tol:g}, drop_null_rows=1, eliminate_dependent_rows=1"
+                    + (", both solves side by side" if paired else ""))
+        entries.sort(key=lambda e: -e["ms_per_step"])
+        for e in entries:
+            e["dominant"] = False
+        hbm = [e for e in entries if e.get("bound") == "hbm"]
+        dominant = hbm[0] if hbm else None
+        if dominant:
+            dominant["dominant"] = True
+        roofline = dict(dominant) if dominant else {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS,
+                                                     "unit": "GB/s", "frac": None, "traffic": None}
+        roofline["traffic_source"] = traffic_files if roofline.get("traffic") else None
+        roofline["selection"] = "the kernel with the largest time per step among those timed on their own (ms_per_step)"
+        scaling = "weak" if (weak or (world > 1 and not slabs)) else "strong"
+        units = world if scaling == "weak" else 1
         out = {
-            "metric": "FLIP substeps/s (hot path; 256^3-sized slab per MI355X) + PCG GB/s",
-            "value": world * args.steps / elapsed,
+            "metric": "FLIP substeps/s (whole substep, side-drop dam break 256^3) + PCG GB/s",
+            "value": units * args.steps / elapsed,
             "unit": "substeps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"dam break {args.n}^3" + (f" x{world} along z" if world > 1 and slabs else "")
-                                   + f", {args.ppc} particles/cell, density projection on, {args.precond} PCG tol {args.tol:g}"
-                                   + (", with level set rebuild, constrain_velocity and advection" if args.full_substep else "")
-                                   + (", both solves side by side" if paired else ""),
-                       "cells": tot_cells, "particles": tot_particles, "rows": tot_rows, "parallelism": parallelism},
+            "config": {"workload": workload, "cells": tot_cells, "particles": tot_particles, "rows": tot_rows, "parallelism": parallelism},
+            "hot_path_only": hot,
             "pcg": {"iterations_per_step": iters / args.steps, "seconds_per_step": pcg_s / args.steps,
                     "effective_GBps": pcg_gbs, "pct_hbm_peak": 100.0 * pcg_gbs / HBM_PEAK_GBS,
                     "bytes_per_row_per_iteration": it_bytes, "rows_this_rank": rows,
                     "converged": all(s["converged"] == 1 for s in solves)},
-            "roofline": {"bound": "hbm", "kernel": "k_pcg_direction", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
-                         "traffic_source": "profiles/r01_d_bench256_mg_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc "
-                                           "passes of this command; 2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)" if traffic else None,
-                         "algorithmic_bytes_per_launch": rows * DIRECTION_BYTES_PER_ROW,
-                         "bytes_per_row": DIRECTION_BYTES_PER_ROW, "rows_per_launch": rows,
-                         "avg_launch_us": avg_launch * 1e6 if avg_launch else None, "launches_timed": spmv_n},
-            "roofline_other_kernels": kernels,
+            "roofline": roofline,
+            "roofline_other_kernels": {e["kernel"]: e for e in entries if not e["dominant"]},
         }
         if jacobi_iters is not None:
             # the CPU works on the state the device has reached, not on the fluid at rest: from rest the vectors of the
             # first solve are full of denormals, which the reference's build (no flush-to-zero) crawls through
             sc.pos, sc.vel = ctx.download_particles()
+            sc.phi_fluid = ctx.download("phi_fluid")
             out["cpu_baseline"] = cpu_baseline(sc, args, jacobi_iters)
         print(json.dumps(out))
     ctx.close()

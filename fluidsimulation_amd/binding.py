@@ -62,7 +62,7 @@ EXPORTS = [
     "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_fluid_levelset_from_particles", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
     "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
-    "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solve_pair", "flip_select_system", "flip_project_velocity",
+    "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_project_velocity",
     "flip_project_displacement", "flip_set_slab", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
     "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish", "flip_set_slab_overlap",
     "flip_pcg_dist_precondition", "flip_pcg_dist_combine", "flip_particles_reserve", "flip_particles_pack",
@@ -120,6 +120,7 @@ def load_library(path: str = LIB_PATH):
         "flip_pcg_solve": (C.c_int, [vp, f64, i32, C.c_int, P(PcgInfo)]),
         "flip_apply_operator": (C.c_int, [vp, vp, vp]),
         "flip_set_profiling": (C.c_int, [vp, C.c_int]),
+        "flip_solver_kernel_times": (C.c_int, [vp, P(f64)]),
         "flip_solve_pair": (C.c_int, [vp, f32, f64, i32, C.c_int, P(PcgInfo), P(PcgInfo)]),
         "flip_select_system": (C.c_int, [vp, C.c_int]),
         "flip_project_velocity": (C.c_int, [vp, f32]),
@@ -333,6 +334,12 @@ class FlipContext:
 
     def set_profiling(self, on: bool):
         self._check(self.lib.flip_set_profiling(self.h, 1 if on else 0))
+
+    def solver_kernel_times(self):
+        """Microseconds of the level-0 kernels of one profiled solver iteration (see flip_solver_kernel_times)."""
+        out = (C.c_double * 6)()
+        self._check(self.lib.flip_solver_kernel_times(self.h, out))
+        return dict(zip(("k_pcg_direction", "k_pcg_update_pre", "k_mg_restrict", "coarse_levels", "k_mg_post", "k_mg_smooth"), out[:]))
 
     def project_velocity(self, dt: float):
         self._check(self.lib.flip_project_velocity(self.h, dt))

@@ -131,6 +131,8 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
         if (c->pair_stream[q]) (void)hipStreamDestroy(c->pair_stream[q]);
     for (int q = 0; q < 3; ++q)
         if (c->pair_event[q]) (void)hipEventDestroy(c->pair_event[q]);
+    for (hipEvent_t e : c->kprof)
+        if (e) (void)hipEventDestroy(e);
     dfree(c->cell_start); dfree(c->cell_fill); dfree(c->sub_start); dfree(c->scan_tmp);
     dfree(c->phi_fluid); dfree(c->phi_solid); dfree(c->phi_obj);
     for (int b = 0; b < 4; ++b)

@@ -182,6 +182,12 @@ struct flip_ctx {
     double *d_vmax = nullptr;       // [3*FLIP_MAX_PCG_BLOCKS]
     bool profiling = false;
     std::vector<hipEvent_t> events;
+    // flip_set_profiling: one iteration of a solve has its level-0 kernels bracketed one by one (kprof_arm is set for
+    // that iteration only; the V-cycle records its own marks): 0 start, 1 after the direction kernel, 2 after the
+    // update (+ pre-smoothing), 3 after the level-0 restriction, 4 after the coarse levels, 5 after the level-0
+    // correction + first post-smoothing step, 6 after the second
+    hipEvent_t kprof[7] = {};
+    bool kprof_arm = false, kprof_valid = false;
     std::vector<flip_mg_level> mg;  // coarse levels, finest first
     float *mg_diag_f = nullptr, *mg_inv_f = nullptr; // float copies of cg_diag / cg_inv for the V-cycle's level 0 (one allocation)
     // one batch of solver iterations as an instantiated graph (the kernels' arguments do not change from solve to

@@ -520,8 +520,11 @@ int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed) {
     const size_t nl = ctx->mg.size();
     MgDev<float> L0 = mg_level0(ctx);
     // ---- down: pre-smooth (result in x), restrict the residual ----
+    const bool mark = ctx->kprof_arm;
     if (!pre_smoothed) k_mg_pre<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.x);
+    if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[2], st));
     k_mg_restrict<float><<<mg_blocks(ctx, ctx->mg[0].B * 8), FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x);
+    if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[3], st));
     for (size_t l = 0; l + 1 < nl; ++l) {
         MgDev<double> F = mg_level(ctx->mg[l]);
         k_mg_pre<double><<<mg_blocks(ctx, ctx->mg[l].B), FLIP_BLOCK, 0, st>>>(F, done, F.x);
@@ -541,11 +544,14 @@ int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed) {
         k_mg_post<double><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x, F.t);
         k_mg_smooth<double, false><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.t, F.x, nullptr);
     }
+    if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[4], st));
     k_mg_post<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x, L0.t);
+    if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[5], st));
     if (ctx->slab_on && ctx->slab_overlap > 0) // r.z waits for the neighbours' share of z (flip_pcg_dist_combine)
         k_mg_smooth<float, false><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.t, L0.x, nullptr);
     else
         k_mg_smooth<float, true><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.t, L0.x, ctx->partial + 1 * FLIP_MAX_PCG_BLOCKS);
+    if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[6], st));
     FLIP_LAUNCH_CHECK();
     return 0;
 }

@@ -794,6 +794,10 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
     FLIP_CHECK(hipMemsetAsync(ctx->z, 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->pv[0], 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->pv[1], 0, (size_t)ctx->B * 8, st));
+    // the residual buffers are read at the six neighbours of a row; a cell that was a row of an earlier solve must not
+    // hand a stale (possibly non-finite) value to a zero coupling
+    FLIP_CHECK(hipMemsetAsync(ctx->r, 0, (size_t)ctx->B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(ctx->r2, 0, (size_t)ctx->B * 8, st));
     if (use_mg) {
         FLIP_CHECK(hipMemsetAsync(ctx->ap, 0, (size_t)ctx->B * 8, st)); // V-cycle scratch on level 0
         if (int rc = flip_mg_setup(ctx)) return rc;
@@ -881,10 +885,19 @@ static int pcg_batch_direct(flip_ctx *ctx, PcgRun &run, int batch, bool allow_ev
     const int nblk = ctx->pcg_blocks;
     for (int b = 0; b < batch; ++b) {
         const bool prof = allow_events && run.n_prof < 64;
+        // the first bracketed iteration of a multigrid solve also has every level-0 kernel timed on its own
+        const bool marks = prof && run.n_prof == 0 && run.use_mg;
+        if (marks) {
+            for (hipEvent_t &e : ctx->kprof)
+                if (!e) FLIP_CHECK(hipEventCreate(&e));
+            FLIP_CHECK(hipEventRecord(ctx->kprof[0], st));
+        }
         if (prof) FLIP_CHECK(hipEventRecord(ctx->events[2 + 2 * run.n_prof], st));
         if (run.sym) k_pcg_direction<true><<<nblk, FLIP_BLOCK, 0, st>>>(A);
         else k_pcg_direction<false><<<nblk, FLIP_BLOCK, 0, st>>>(A);
         if (prof) { FLIP_CHECK(hipEventRecord(ctx->events[3 + 2 * run.n_prof], st)); ++run.n_prof; }
+        if (marks) FLIP_CHECK(hipEventRecord(ctx->kprof[1], st));
+        ctx->kprof_arm = marks;
         if (run.fused) {
             FusedArgs F;
             F.inv_f = ctx->mg_inv_f; F.diag_f = ctx->mg_diag_f; F.r2 = ctx->r2;
@@ -896,6 +909,7 @@ static int pcg_batch_direct(flip_ctx *ctx, PcgRun &run, int batch, bool allow_ev
             if (run.use_mg)
                 if (int rc = flip_mg_vcycle(ctx)) return rc;
         }
+        if (marks) { ctx->kprof_arm = false; ctx->kprof_valid = true; }
     }
     FLIP_LAUNCH_CHECK();
     run.launched += batch;
@@ -1061,6 +1075,19 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
     rc = pcg_report(ctx, run[1], tail[1], info_density);
     flip_swap_systems(ctx);
     return rc;
+}
+
+extern "C" int flip_solver_kernel_times(flip_ctx *ctx, double us[6]) {
+    FLIP_REQUIRE(ctx && us, "flip_solver_kernel_times: null argument");
+    FLIP_REQUIRE(ctx->kprof_valid, "flip_solver_kernel_times: no profiled multigrid solve yet (flip_set_profiling, then a solve)");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    FLIP_CHECK(hipEventSynchronize(ctx->kprof[6]));
+    for (int q = 0; q < 6; ++q) {
+        float ms = 0.f;
+        FLIP_CHECK(hipEventElapsedTime(&ms, ctx->kprof[q], ctx->kprof[q + 1]));
+        us[q] = (double)ms * 1e3;
+    }
+    return 0;
 }
 
 extern "C" int flip_select_system(flip_ctx *ctx, int kind) {

@@ -38,6 +38,28 @@ class SlabLayout:
             assert self.starts[r + 1] - self.starts[r] >= max(ghost, 1) or world == 1, \
                 "a slab must be at least as thick as the ghost zone, so that ghosts reach only the next rank"
 
+    @classmethod
+    def balanced(cls, weights, world: int, ghost: int):
+        """Split so that every rank owns about the same total weight (e.g. particles per plane): a dam break does not
+        fill the planes inside the container walls, and an even split would leave the end ranks nearly idle.  Every
+        slab stays at least as thick as the ghost zone."""
+        w = np.asarray(weights, dtype=np.float64)
+        nz = int(w.size)
+        if world == 1:
+            return cls(nz, 1, ghost)
+        cum = np.concatenate([[0.0], np.cumsum(w)])
+        total = cum[-1] if cum[-1] > 0 else 1.0
+        min_thick = max(int(ghost), 1)
+        assert nz >= world * min_thick, "more ranks than slabs of ghost thickness fit into the box"
+        starts = [0]
+        for r in range(1, world):
+            k = int(np.searchsorted(cum, total * r / world))
+            k = max(k, starts[-1] + min_thick)              # thick enough
+            k = min(k, nz - (world - r) * min_thick)         # and room for the ranks that follow
+            starts.append(k)
+        starts.append(nz)
+        return cls(nz, world, ghost, starts=starts)
+
     def owned(self, rank: int):
         return self.starts[rank], self.starts[rank + 1]
 
@@ -308,15 +330,19 @@ class ParticleExchange:
 
 class DistributedSubstep:
     """FlipSubstep over a slab decomposition: the same call order (src/FluidSimulator.cpp:307-446), with the two
-    solves replaced by slab_pcg_solve and a particle exchange at the end of the substep."""
+    solves replaced by slab_pcg_solve and a particle exchange at the end of the substep.  `constrain`, `advect` and
+    `levelset_radius` switch on the same optional stages as in FlipSubstep; each reaches only a few cells sideways, so
+    the ghost planes cover them without further communication."""
 
     def __init__(self, ctx, layout: SlabLayout, comm: Comm, device: int = 0, flip_pic_ratio: float = 0.95,
                  tol: float = 1e-15, max_iter: int = 20000, precond: int = PRECOND_MULTIGRID,
-                 density_projection: bool = True, overlap: int = 0):
+                 density_projection: bool = True, overlap: int = 0, constrain: bool = False, advect: bool = False,
+                 levelset_radius: float | None = None):
         self.ctx, self.layout, self.comm = ctx, layout, comm
         self.solver = ContextSlabSolver(ctx, layout, comm.rank, device, overlap=overlap)
         self.ratio, self.tol, self.max_iter, self.precond = flip_pic_ratio, tol, max_iter, precond
         self.density_projection = density_projection
+        self.constrain, self.advect, self.levelset_radius = constrain, advect, levelset_radius
         # a message holds at most the sender's authoritative particles; slabs hold similar numbers of them
         self.exchange = ParticleExchange(ctx, self.solver, comm, device, capacity=ctx.particle_count() * 5 // 4 + 4096) \
             if comm.world > 1 else None
@@ -328,9 +354,13 @@ class DistributedSubstep:
     def step(self, dt: float) -> dict:
         c = self.ctx
         c.bin_particles(want_outside=False)
+        if self.levelset_radius is not None:
+            c.fluid_levelset_from_particles(self.levelset_radius)   # :324
         c.p2g()
         c.mark_valid_from_active()
         c.extrapolate(2)
+        if self.constrain:
+            c.constrain_velocity(False)                             # :357
         c.update_prev()
         c.add_forces(dt)
         c.index_cells()
@@ -342,8 +372,12 @@ class DistributedSubstep:
             out["density"] = self.solve(SOLVE_DENSITY, dt)
             c.project_displacement(dt)
         c.extrapolate(2)
+        if self.constrain:
+            c.constrain_velocity(False)                             # :404
         c.update_diff()
         c.g2p(self.ratio)
+        if self.advect:
+            c.advect_particles(dt)                                  # :426
         if self.density_projection:
             c.apply_displacements()
         if self.exchange is not None:

@@ -209,22 +209,29 @@ def dam_break(n: int, ppc: int = 8, seed: int = 12345, exact_levelset: bool = Tr
     return sc
 
 
-def dam_break_slab(n: int, ppc: int = 8, seed: int = 12345, z_repeat: int = 1, z_planes=None) -> Scene:
+def dam_break_slab(n: int, ppc: int = 8, seed: int = 12345, z_repeat: int = 1, z_planes=None, full_domain: bool = False) -> Scene:
     """The dam-break column in a container ``z_repeat`` times as long along z, restricted to the planes
     ``z_planes = (e0, e1)`` of its dense box (None: all of it).  Particles come plane by plane from
     (seed, plane)-seeded generators and the level set is the analytic stand-in, so a rank can build its slab
-    alone and neighbouring ranks agree on the planes they share."""
-    sc = container(n, z_repeat=z_repeat, z_planes=z_planes)
-    lo = (n // 4, 1, n // 4)
-    hi = (n // 2, 3 * n // 4, n // 4 + z_repeat * (n // 2) + 1)
+    alone and neighbouring ranks agree on the planes they share.  ``full_domain``: the container spans the whole
+    nominal grid (walls at 1 and n-2 on every axis) and the column fills its lower-x half to 3/4 of the height:
+    at n = 512 and 16 particles per cell that is the ~1e9-particle case."""
+    sc = container(n, full_domain=full_domain, z_repeat=z_repeat, z_planes=z_planes)
+    if full_domain:
+        lo = (1, 1, 1)
+        hi = (n // 2, 3 * n // 4, 1 + z_repeat * (n - 3) + 1)
+    else:
+        lo = (n // 4, 1, n // 4)
+        hi = (n // 2, 3 * n // 4, n // 4 + z_repeat * (n // 2) + 1)
     sc.pos, sc.vel, sc.mass = _fill_cells_by_plane(sc, lo, hi, ppc, seed)
     sc.phi_fluid = fluid_levelset_box(sc, lo, hi)
     return sc
 
 
-def slab_box_planes(n: int, z_repeat: int = 1) -> int:
-    """Number of z planes of the dense box of ``dam_break_slab(n, z_repeat=z_repeat)``."""
-    return z_repeat * (n // 2) + 2 * SOLID_HALF_WIDTH + 1
+def slab_box_planes(n: int, z_repeat: int = 1, full_domain: bool = False) -> int:
+    """Number of z planes of the dense box of ``dam_break_slab(n, z_repeat=z_repeat, full_domain=full_domain)``."""
+    open_planes = (n - 3) if full_domain else (n // 2)
+    return z_repeat * open_planes + 2 * SOLID_HALF_WIDTH + 1
 
 
 def add_sphere(sc: Scene, radius_world: float = 0.1, centre_world=(0.5, 0.5, 0.5), density: float = 250.0,

@@ -246,6 +246,12 @@ int flip_apply_operator(flip_ctx *ctx, const double *x_host, double *y_host);
 /* When enabled, flip_pcg_solve brackets a sample of its operator launches with HIP events and
  * reports their total in flip_pcg_info::spmv_seconds. */
 int flip_set_profiling(flip_ctx *ctx, int enabled);
+/* With profiling enabled, the first bracketed iteration of a multigrid solve also has each of its level-0 kernels
+ * timed on its own (HIP events on the solve's stream, nothing else running on the device in flip_solve_pair).
+ * us[0] operator + direction kernel, us[1] update + pre-smoothing, us[2] level-0 restriction, us[3] all coarse
+ * levels together, us[4] level-0 correction + first post-smoothing step, us[5] second post-smoothing step (+ r.z).
+ * Measurement aid; no counterpart in the reference (its timings are wall-clock printfs, src/FluidSimulator.cpp:437). */
+int flip_solver_kernel_times(flip_ctx *ctx, double us[6]);
 
 /* ---- z-slab decomposition of the solve over several GPUs (one process and one context per GPU) ----------
  * No counterpart in the reference, which is a single-process CPU program.  Each rank's box is its slab of

@@ -225,6 +225,15 @@ def test_slab_layout_and_partition():
     assert lay.extended(0) == (0, 16) and lay.extended(2) == (14, 36) and lay.local_owned(2) == (6, 16)
     with pytest.raises(AssertionError):
         SlabLayout(40, 8, 6)     # slabs thinner than the ghost zone
+    # cut by load: the planes inside the walls weigh little, every slab stays at least as thick as the ghost zone
+    w = np.full(138, 0.1)
+    w[5:-5] = 1.0
+    bal = SlabLayout.balanced(w, 8, 8)
+    thick = [bal.owned(r)[1] - bal.owned(r)[0] for r in range(8)]
+    assert sum(thick) == 138 and min(thick) >= 8 and thick[0] > thick[3] and thick[-1] > thick[3]
+    loads = [w[bal.owned(r)[0]:bal.owned(r)[1]].sum() for r in range(8)]
+    assert max(loads) - min(loads) <= 2.0
+    assert [SlabLayout.balanced(np.ones(16), 2, 8).owned(r) for r in range(2)] == [(0, 8), (8, 16)]
     sc = _scene()
     lay = SlabLayout(sc.dims[2], 2, GHOST)
     parts = [partition_scene(sc, lay, r) for r in range(2)]
@@ -284,7 +293,7 @@ def test_two_rank_slab_solve_matches_the_global_solve(tmp_path, overlap):
 # ------------------------------------------------------------------------------------------------
 # GPU: two ranks on the one device of the box, real kernels, gloo with host staging
 
-def _gpu_worker(rank, port, out_dir, precond, kind, overlap):
+def _gpu_worker(rank, port, out_dir, precond, kind, overlap, full=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -293,7 +302,7 @@ def _gpu_worker(rank, port, out_dir, precond, kind, overlap):
     from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout, partition_scene
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=WORLD)
     try:
-        _gpu_rank_body(rank, out_dir, precond, kind, overlap)
+        _gpu_rank_body(rank, out_dir, precond, kind, overlap, full)
     except BaseException:
         import traceback
         with open(os.path.join(out_dir, f"error_{rank}.txt"), "w") as f:
@@ -303,19 +312,19 @@ def _gpu_worker(rank, port, out_dir, precond, kind, overlap):
         dist.destroy_process_group()
 
 
-def _gpu_rank_body(rank, out_dir, precond, kind, overlap):
+def _gpu_rank_body(rank, out_dir, precond, kind, overlap, full=False):
     import torch
     from fluidsimulation_amd import FlipContext
     from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout, partition_scene
     if True:
         torch.cuda.set_device(0)
         sc = _scene_gpu(kind)
-        layout = SlabLayout(sc.dims[2], WORLD, 8)
+        layout = _gpu_layout(sc, kind)
         loc = partition_scene(sc, layout, rank)
         with FlipContext(loc.desc(), device=0) as ctx:
             ctx.reserve_particles(2 * loc.pos.shape[0])
             ctx.upload_scene(loc)
-            step = DistributedSubstep(ctx, layout, Comm(), device=0, precond=precond, max_iter=20000, overlap=overlap)
+            step = DistributedSubstep(ctx, layout, Comm(), device=0, precond=precond, max_iter=20000, overlap=overlap, **_extras(sc, full))
             info = step.step(0.004)
             p = ctx.download("pressure")
             # after the exchange the set holds this rank's owned particles and fresh ghost copies
@@ -334,9 +343,30 @@ def _gpu_rank_body(rank, out_dir, precond, kind, overlap):
                  iterations=info["divergence"]["iterations"])
 
 
+def _extras(sc, full):
+    """The optional stages of the whole substep: level set from the particles, constrain_velocity, RK3 advection."""
+    if not full:
+        return {}
+    return dict(constrain=True, advect=True, levelset_radius=1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0)
+
+
+def _gpu_layout(sc, kind):
+    from fluidsimulation_amd.distributed import SlabLayout
+    if kind == "full_domain":
+        # uneven slabs, cut by load as the strong-scaling benchmark does
+        w = np.full(sc.dims[2], 0.1)
+        w[5:-5] = 1.0
+        w[: sc.dims[2] // 3] *= 2.0
+        return SlabLayout.balanced(w, WORLD, 8)
+    return SlabLayout(sc.dims[2], WORLD, 8)
+
+
 def _scene_gpu(kind="dam"):
     from fluidsimulation_amd import scenes
-    if kind == "long":
+    if kind == "full_domain":
+        # the 512^3 configuration's scene (container over the whole nominal grid) at reduced size
+        sc = scenes.dam_break_slab(24, ppc=8, seed=12345, full_domain=True)
+    elif kind == "long":
         # the benchmark's multi-GPU scene: slab faces at odd planes, so coarse multigrid cells straddle them
         sc = scenes.dam_break_slab(32, ppc=8, seed=12345, z_repeat=2)
     else:
@@ -347,14 +377,16 @@ def _scene_gpu(kind="dam"):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precond,kind,overlap", [(0, "dam", 0), (1, "dam", 0), (1, "long", 0), (1, "dam", 8), (1, "long", 5), (0, "dam", 2)])
-def test_two_ranks_on_one_gpu_match_the_single_context_substep(tmp_path, precond, kind, overlap):
+@pytest.mark.parametrize("precond,kind,overlap,full", [(0, "dam", 0, False), (1, "dam", 0, False), (1, "long", 0, False), (1, "dam", 8, False),
+                                                       (1, "long", 5, False), (0, "dam", 2, False), (1, "dam", 4, True),
+                                                       (1, "full_domain", 4, True)])
+def test_two_ranks_on_one_gpu_match_the_single_context_substep(tmp_path, precond, kind, overlap, full):
     import torch.multiprocessing as mp
     from fluidsimulation_amd import FlipContext, FlipSubstep
     from fluidsimulation_amd.distributed import SlabLayout
     port = _free_port()
     try:
-        mp.spawn(_gpu_worker, args=(port, str(tmp_path), precond, kind, overlap), nprocs=WORLD, join=True)
+        mp.spawn(_gpu_worker, args=(port, str(tmp_path), precond, kind, overlap, full), nprocs=WORLD, join=True)
     except Exception:
         for r in range(WORLD):
             f = os.path.join(str(tmp_path), f"error_{r}.txt")
@@ -364,15 +396,15 @@ def test_two_ranks_on_one_gpu_match_the_single_context_substep(tmp_path, precond
     sc = _scene_gpu(kind)
     with FlipContext(sc.desc()) as ctx:
         ctx.upload_scene(sc)
-        ref_info = FlipSubstep(ctx, precond=precond, max_iter=20000).step(0.004)
+        ref_info = FlipSubstep(ctx, precond=precond, max_iter=20000, **_extras(sc, full)).step(0.004)
         ref_pos, ref_vel = ctx.download_particles()
         ref_p = ctx.download("pressure")
     assert ref_info["divergence"]["converged"] == 1
-    lay = SlabLayout(sc.dims[2], WORLD, 8)
+    lay = _gpu_layout(sc, kind)
     from scipy.spatial import cKDTree
     with FlipContext(sc.desc()) as ctx:
         ctx.upload_scene(sc)
-        stepper = FlipSubstep(ctx, precond=precond, max_iter=20000)
+        stepper = FlipSubstep(ctx, precond=precond, max_iter=20000, **_extras(sc, full))
         stepper.step(0.004)
         stepper.step(0.004)
         ref_pos2, ref_vel2 = ctx.download_particles()

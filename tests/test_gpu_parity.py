@@ -604,3 +604,33 @@ def test_p2g_on_a_wide_box_with_a_crowded_line_is_bit_exact():
             assert np.array_equal(ctx.download(name), ref), name
         assert np.array_equal(ctx.download("active").astype(bool), pm2.astype(bool))
         assert np.array_equal(ctx.download("density"), dens)
+
+
+def test_full_domain_dam_break_properties():
+    """The container of the 512^3 configuration (walls at 1 and n-2 on every axis) at reduced size: binning sorted and
+    complete, both solves converged to the reference tolerance, particles stay inside the container over several whole
+    substeps."""
+    from fluidsimulation_amd import FlipSubstep, PRECOND_MULTIGRID
+    sc = scenes.dam_break(48, ppc=8, seed=3, exact_levelset=False, full_domain=True)
+    radius = 1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        assert ctx.bin_particles() == 0
+        cell_id, cell_start, perm = ctx.download_binning()
+        assert np.all(np.diff(cell_start) >= 0) and cell_start[-1] == sc.pos.shape[0]
+        assert np.all(np.diff(cell_id[perm]) >= 0)                       # slots ascend by cell
+        assert np.array_equal(np.sort(perm), np.arange(sc.pos.shape[0]))  # every particle once
+        o = Oracle(sc.desc())
+        want_id, want_start, want_perm, _ = o.bin_particles(sc.pos)
+        assert np.array_equal(cell_id, want_id) and np.array_equal(cell_start, want_start) and np.array_equal(perm, want_perm)
+        step = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, max_iter=5000, concurrent_solves=True, constrain=True, advect=True,
+                           levelset_radius=radius)
+        for _ in range(3):
+            info = step.step(0.004)
+            for k in ("divergence", "density"):
+                assert info[k]["converged"] == 1 and info[k]["rel_residual_2"] < RES_TOL
+        pos, vel = ctx.download_particles()
+        assert np.isfinite(pos).all() and np.isfinite(vel).all()
+        lo, hi = np.asarray(sc.box_lo), np.asarray(sc.box_hi)
+        assert np.all(pos > lo - 0.5) and np.all(pos < hi + 0.5)
+        assert ctx.bin_particles() == 0
