@@ -87,15 +87,26 @@ def parse():
 
 
 def spawn_ranks(n):
-    """Starts this script under torch.distributed.run with n ranks (before anything here has touched a GPU) and returns
-    its exit code."""
+    """Starts n rank processes of this script (before anything here has touched a GPU), with the rendezvous variables
+    torch.distributed expects, and returns the first non-zero exit code (0 if all succeeded)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        code = p.wait()
+        if code != 0 and rc == 0:
+            rc = code
+            for q in procs:      # a rank that failed leaves the others waiting in a collective
+                if q.poll() is None:
+                    q.terminate()
+    return rc
 
 
 def cpu_stage_seconds(o, sc, args):
