@@ -60,7 +60,7 @@ EXPORTS = [
     "flip_particles_upload", "flip_particles_download", "flip_particles_count", "flip_bin_particles",
     "flip_binning_download", "flip_field_upload", "flip_field_download", "flip_field_bytes", "flip_p2g", "flip_g2p",
     "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_fluid_levelset_from_particles", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
-    "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_index_cells", "flip_face_fractions",
+    "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_velocity_max_static", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
     "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_project_velocity",
     "flip_project_displacement", "flip_set_slab", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
@@ -109,6 +109,7 @@ def load_library(path: str = LIB_PATH):
         "flip_update_prev": (C.c_int, [vp]),
         "flip_update_diff": (C.c_int, [vp]),
         "flip_velocity_max": (C.c_int, [vp, P(f64)]),
+        "flip_velocity_max_static": (C.c_int, [vp, P(f64)]),
         "flip_index_cells": (C.c_int, [vp, P(i32)]),
         "flip_face_fractions": (C.c_int, [vp]),
         "flip_density": (C.c_int, [vp, P(i64)]),
@@ -266,6 +267,12 @@ class FlipContext:
     def velocity_max(self):
         out = (C.c_double * 3)()
         self._check(self.lib.flip_velocity_max(self.h, out))
+        return np.array(out[:], dtype=np.float64)
+
+    def velocity_max_static(self):
+        """flip_velocity_max through the entry point that allocates nothing (static device workspace)."""
+        out = (C.c_double * 3)()
+        self._check(self.lib.flip_velocity_max_static(self.h, out))
         return np.array(out[:], dtype=np.float64)
 
     def index_cells(self) -> int:

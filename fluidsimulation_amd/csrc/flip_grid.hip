@@ -368,6 +368,69 @@ extern "C" int flip_velocity_max(flip_ctx *ctx, double out_max[3]) {
     return 0;
 }
 
+// The same reduction for callers that must not allocate (code under HIP graph capture, serving loops, harnesses that
+// forbid hipMalloc): the per-workgroup partial maxima live in a file-scope device array instead of memory the library
+// allocated, and the host side uses no container.  The array's name is only a host-side handle: its device address is
+// looked up once per device with hipGetSymbolAddress and kept; every GPU holds its own copy at its own address.
+#define FLIP_STATIC_VMAX_BLOCKS 4096          // workgroups at most
+#define FLIP_STATIC_VMAX_CELLS_PER_BLOCK 16384 // 256 threads x 64 cells
+#define FLIP_STATIC_VMAX_MAX_DEVICES 64
+// [3][FLIP_STATIC_VMAX_BLOCKS] partial maxima, then the 3 results: 96 KB + 256 B per GPU, held until the process ends
+static __device__ __align__(256) double flip_static_vmax_scratch[3 * FLIP_STATIC_VMAX_BLOCKS + 32];
+static double *g_static_vmax_ptr[FLIP_STATIC_VMAX_MAX_DEVICES] = {};
+
+__global__ void __launch_bounds__(FLIP_BLOCK) k_vel_max_static(long long B, const uint8_t *__restrict__ active, const double *__restrict__ u,
+                                                              const double *__restrict__ v, const double *__restrict__ w,
+                                                              double *__restrict__ part) {
+    __shared__ double scratch[4];
+    double m0 = -1e300, m1 = -1e300, m2 = -1e300;
+    const long long lo = (long long)blockIdx.x * FLIP_STATIC_VMAX_CELLS_PER_BLOCK;
+    const long long hi = lo + FLIP_STATIC_VMAX_CELLS_PER_BLOCK < B ? lo + FLIP_STATIC_VMAX_CELLS_PER_BLOCK : B;
+    for (long long c = lo + threadIdx.x; c < hi; c += FLIP_BLOCK)
+        if (active[c]) { m0 = fmax(m0, u[c]); m1 = fmax(m1, v[c]); m2 = fmax(m2, w[c]); }
+    m0 = d_block_max(m0, scratch);
+    m1 = d_block_max(m1, scratch);
+    m2 = d_block_max(m2, scratch);
+    // every workgroup of the launch writes its three slots, so nothing a previous call left behind is ever read
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = m0;
+        part[FLIP_STATIC_VMAX_BLOCKS + blockIdx.x] = m1;
+        part[2 * FLIP_STATIC_VMAX_BLOCKS + blockIdx.x] = m2;
+    }
+}
+__global__ void __launch_bounds__(FLIP_BLOCK) k_vel_max_static_final(int nblk, double *__restrict__ part) {
+    __shared__ double scratch[4];
+    for (int a = 0; a < 3; ++a) {
+        double m = -1e300;
+        for (int q = threadIdx.x; q < nblk; q += FLIP_BLOCK) m = fmax(m, part[a * FLIP_STATIC_VMAX_BLOCKS + q]);
+        m = d_block_max(m, scratch);
+        if (threadIdx.x == 0) part[3 * FLIP_STATIC_VMAX_BLOCKS + a] = m == -1e300 ? 0.0 : m;
+    }
+}
+
+extern "C" int flip_velocity_max_static(flip_ctx *ctx, double out_max[3]) {
+    FLIP_REQUIRE(ctx && out_max, "flip_velocity_max_static: null argument");
+    FLIP_REQUIRE(ctx->B <= (int64_t)FLIP_STATIC_VMAX_BLOCKS * FLIP_STATIC_VMAX_CELLS_PER_BLOCK,
+                 "flip_velocity_max_static: the box has more than 67108864 cells, the limit of the static workspace "
+                 "(use flip_velocity_max)");
+    FLIP_REQUIRE(ctx->device >= 0 && ctx->device < FLIP_STATIC_VMAX_MAX_DEVICES, "flip_velocity_max_static: device index beyond 63");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    double *part = g_static_vmax_ptr[ctx->device];
+    if (!part) {
+        // first call on this device, with this device current: the address of this GPU's copy of the array
+        FLIP_CHECK(hipGetSymbolAddress((void **)&part, HIP_SYMBOL(flip_static_vmax_scratch)));
+        FLIP_REQUIRE(part != nullptr, "flip_velocity_max_static: no device address for the static workspace");
+        g_static_vmax_ptr[ctx->device] = part;
+    }
+    const int nblk = (int)((ctx->B + FLIP_STATIC_VMAX_CELLS_PER_BLOCK - 1) / FLIP_STATIC_VMAX_CELLS_PER_BLOCK);
+    k_vel_max_static<<<nblk, FLIP_BLOCK, 0, ctx->stream>>>(ctx->B, ctx->active, ctx->vel[0][0], ctx->vel[0][1], ctx->vel[0][2], part);
+    k_vel_max_static_final<<<1, FLIP_BLOCK, 0, ctx->stream>>>(nblk, part);
+    FLIP_LAUNCH_CHECK();
+    FLIP_CHECK(hipMemcpyAsync(out_max, part + 3 * FLIP_STATIC_VMAX_BLOCKS, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FLIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // constrain_velocity: src/FluidSimulator.cpp:1180-1247 (container) and :1249-1321 (rigid body).  On every face
 // whose solid fraction is exactly 1 the sampled velocity loses its component along the level set's normal (for
