@@ -822,14 +822,29 @@ __global__ void k_fluid_levelset(GridDims g, int nyb, float vs, double radius, d
         for (int dz = -s; dz <= s; ++dz) {
             const int kk = k + dz;
             if (kk < 0 || kk >= g.nz) continue;
+            const double bz = dz == 0 ? 0.0 : (double)(dz < 0 ? -dz : dz) - 0.5;
             for (int jj = ya; jj <= yb; ++jj) {
                 if (jj < 0 || jj >= g.ny) continue;
+                // Pruning: a particle of cell (ii, jj, kk) is at least (|ii - i| - 1/2, by, bz) away from every cell of the
+                // column, so a cell of this row can only improve a minimum if that bound is below the largest of the
+                // column's current minima: |ii - i| < 1/2 + sqrt(worst - by^2 - bz^2).  Cells far from the liquid would
+                // otherwise walk every particle within their last shell; the minimum itself is unchanged (the cells
+                // skipped hold no candidate).
+                double worst = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) worst = (j0 + r < g.ny && best2[r] > worst) ? best2[r] : worst;
+                const int dyc = jj < j0 ? j0 - jj : (jj > j1 ? jj - j1 : 0);
+                const double by = dyc == 0 ? 0.0 : (double)dyc - 0.5;
+                const double room = worst - by * by - bz * bz;
+                if (!(room > 0.0)) continue;
+                const int xr = room > 1e12 ? s : (int)(0.5 + sqrt(room) + 1e-9); // cells |ii - i| <= xr may hold a candidate
                 const long long row = (long long)g.nx * ((long long)jj + (long long)g.ny * kk);
                 const bool face = dz == -s || dz == s || jj == ya || jj == yb; // the whole x run lies on the shell
                 if (face) {
-                    const int xa = i - s > 0 ? i - s : 0, xb = i + s < g.nx - 1 ? i + s : g.nx - 1;
+                    const int h = xr < s ? xr : s;
+                    const int xa = i - h > 0 ? i - h : 0, xb = i + h < g.nx - 1 ? i + h : g.nx - 1;
                     d_ls_range<R>(pm, cell_start[row + xa], cell_start[row + xb + 1], cx, cy, cz, best2);
-                } else {
+                } else if (s <= xr) {
                     if (i - s >= 0) d_ls_range<R>(pm, cell_start[row + i - s], cell_start[row + i - s + 1], cx, cy, cz, best2);
                     if (s > 0 && i + s < g.nx) d_ls_range<R>(pm, cell_start[row + i + s], cell_start[row + i + s + 1], cx, cy, cz, best2);
                 }
