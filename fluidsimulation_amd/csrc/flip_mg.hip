@@ -100,13 +100,12 @@ __device__ __forceinline__ double d_mg_apply(const MgDev<CT> &L, long long c, co
 // Pre-smoothing, both steps of the smoother from a zero guess in one kernel:
 //   t = C1 D^-1 b  (evaluated on the fly at the 7 stencil points),  out = t + A2 t + C2 D^-1 (b - A t)
 template <class CT>
-__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_pre(MgDev<CT> L, const int32_t *done, double *__restrict__ out) {
-    if (done && *done) return;
+__device__ __forceinline__ void d_mg_pre(const MgDev<CT> &L, double *__restrict__ out, long long first, long long stride) {
     const long long n = *L.n_rows;
     const CT *__restrict__ inv = L.inv;
     const double *__restrict__ b = d_mg_rhs(L);
 #pragma unroll 2
-    for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
+    for (long long q = first; q < n; q += stride) {
         const long long c = L.rows[q];
         const long long sy = L.sy, sz = L.sz;
         const double bc = b[c], ic = (double)inv[c];
@@ -122,6 +121,11 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_pre(MgDev<CT> L, const int32_
         const double At = (double)L.diag[c] * t0 - L.scale * acc;
         out[c] = t0 + L.a2 * t0 + L.c2 * ic * (bc - At);
     }
+}
+template <class CT>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_pre(MgDev<CT> L, const int32_t *done, double *__restrict__ out) {
+    if (done && *done) return;
+    d_mg_pre(L, out, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK);
 }
 
 // Second post-smoothing step: out = in + A2 (in - v) + C2 D^-1 (b - A in), where v = out_old + P xc is the corrected
@@ -169,18 +173,26 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, MgDev<dou
         }
     }
 }
+__device__ __forceinline__ void d_mg_smooth(const MgDev<double> &L, const MgDev<double> &C, const double *__restrict__ in, double *out,
+                                            long long first, long long stride) {
+    const long long n = *L.n_rows;
+    const double *__restrict__ rhs = L.b;
+    for (long long q = first; q < n; q += stride) {
+        const long long c = L.rows[q];
+        out[c] = d_mg_second_step(L, C, c, in, out, rhs[c]);
+    }
+}
 
 // Coarse correction + first post-smoothing step in one kernel: with v = in + P xc (the parent's value
 // added on the fly at the 7 stencil points), out = v + C1 D^-1 (b - A v).
 template <class CT>
-__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post(MgDev<CT> F, MgDev<double> C, const int32_t *done,
-                                                       const double *__restrict__ in, double *__restrict__ out) {
-    if (done && *done) return;
+__device__ __forceinline__ void d_mg_post(const MgDev<CT> &F, const MgDev<double> &C, const double *__restrict__ in, double *__restrict__ out,
+                                          long long first, long long stride) {
     const long long n = *F.n_rows;
     const double *__restrict__ xc = C.x;
     const double *__restrict__ rhs = d_mg_rhs(F);
 #pragma unroll 2
-    for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
+    for (long long q = first; q < n; q += stride) {
         const long long c = F.rows[q];
         const unsigned cu = (unsigned)c, tq = cu / (unsigned)F.nx;
         const int i = (int)(cu - tq * (unsigned)F.nx);
@@ -205,19 +217,23 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post(MgDev<CT> F, MgDev<doubl
         out[c] = v0 + F.c1 * (double)F.inv[c] * (rhs[c] - Av);
     }
 }
+template <class CT>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post(MgDev<CT> F, MgDev<double> C, const int32_t *done,
+                                                       const double *__restrict__ in, double *__restrict__ out) {
+    if (done && *done) return;
+    d_mg_post(F, C, in, out, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK);
+}
 
 // coarse b = sum over the eight children of (b - A v) on the fine level.  Eight lanes per coarse row, one per
 // child, summed by three exchange steps in a fixed order.
 template <class CT>
-__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<double> C, const int32_t *done,
-                                                           const double *__restrict__ v) {
-    if (done && *done) return;
+__device__ __forceinline__ void d_mg_restrict(const MgDev<CT> &F, const MgDev<double> &C, const double *__restrict__ v, long long first_thread,
+                                              long long total_threads) {
     const long long n = *C.n_rows;
     const double *__restrict__ rhs = d_mg_rhs(F);
     const int child = threadIdx.x & 7;
     const int di = child & 1, dj = (child >> 1) & 1, dk = child >> 2;
-    for (long long q = ((long long)blockIdx.x * FLIP_BLOCK + threadIdx.x) >> 3; q < ((n + 31) & ~31LL);
-         q += ((long long)gridDim.x * FLIP_BLOCK) >> 3) {
+    for (long long q = first_thread >> 3; q < ((n + 31) & ~31LL); q += total_threads >> 3) {
         double s = 0.0;
         long long cc = 0;
         if (q < n) {
@@ -237,6 +253,12 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<d
         if (q < n && child == 0) C.b[cc] = s;
     }
 }
+template <class CT>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<double> C, const int32_t *done,
+                                                           const double *__restrict__ v) {
+    if (done && *done) return;
+    d_mg_restrict(F, C, v, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK);
+}
 
 // Coarsest level: one workgroup, vectors in LDS (dense over the level's cells, zero-padded so that the
 // stencil needs no bounds test), a fixed number of Chebyshev sweeps on D^-1 A from zero.  The spectrum of
@@ -245,9 +267,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<d
 // definite operator, as CG requires of its preconditioner.  Each thread keeps the coefficients of its
 // (at most 4) cells in registers:
 //   x_{k+1} = x_k + a_k (x_k - x_{k-1}) + c_k D^-1 (b - A x_k)
-__global__ void __launch_bounds__(1024) k_mg_coarsest(MgDev<double> L, const int32_t *done, int pad) {
-    extern __shared__ double lds[];
-    if (done && *done) return;
+__device__ __forceinline__ void d_mg_coarsest(const MgDev<double> &L, int pad, double *lds) {
     const int B = (int)L.B, sy = (int)L.sy, sz = (int)L.sz;
     double *xa = lds + pad, *xb = lds + (B + 2 * pad) + pad;
     for (int q = threadIdx.x; q < 2 * (B + 2 * pad); q += blockDim.x) lds[q] = 0.0;
@@ -305,6 +325,11 @@ __global__ void __launch_bounds__(1024) k_mg_coarsest(MgDev<double> L, const int
         const int c = threadIdx.x + m * 1024;
         if (c < B) L.x[c] = xa[c];
     }
+}
+__global__ void __launch_bounds__(1024) k_mg_coarsest(MgDev<double> L, const int32_t *done, int pad) {
+    extern __shared__ double lds[];
+    if (done && *done) return;
+    d_mg_coarsest(L, pad, lds);
 }
 
 // Galerkin coarsening with piecewise-constant transfer, scaled by 1/2 (see the header comment).

@@ -405,32 +405,57 @@ struct DensityArgs {
     double vs3;
 };
 
-#define FLIP_GATHER_RUNS 16
-template <bool P2G>
-__global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, const int32_t *__restrict__ sub_start, const uint8_t *__restrict__ band,
+// RY cells of a y-column per thread (1 or 2): the runs around them are walked once for all of them ((2 RY + 2) x 4 runs
+// instead of 16 RY), which removes loads and loop overhead, not arithmetic; every cell still meets its particles in its
+// own order.  Which cells a run feeds travels in the spare top bits of its (first, end) pair.
+// The density term divides by a per-cell constant: a / b is evaluated as q0 = a * y, q = fma(fma(-q0, b, a), y, q0) with
+// y = 1 / b rounded once per cell, which yields the correctly rounded quotient (the residual a - q0 b is exact in the
+// fused operation, and one correction of a product that is already within an ulp lands on the nearest double) at three
+// instructions instead of the fifteen of a division.
+template <bool P2G, int RY>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, int nyb, const int32_t *__restrict__ sub_start, const uint8_t *__restrict__ band,
                                                       const flip_ppos *__restrict__ pm, const flip_pvel *__restrict__ pv,
                                                       double *__restrict__ u, double *__restrict__ v, double *__restrict__ w,
                                                       uint8_t *__restrict__ active, DensityArgs da) {
-    __shared__ int2 runs[FLIP_GATHER_RUNS][FLIP_BLOCK];
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.B) return;
-    if (!(band[c] & 2)) {
-        if (P2G) { u[c] = 0.0; v[c] = 0.0; w[c] = 0.0; active[c] = 0; }
-        da.density[c] = 0.f;
-        return;
-    }
+    constexpr int NRUN = (2 * RY + 2) * 4;
+    __shared__ int2 runs[NRUN][FLIP_BLOCK];
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)g.nx * nyb * g.nz) return;
     const int tid = threadIdx.x;
-    int i, j, k;
-    d_ijk(g, c, i, j, k);
+    const int i = (int)(t % g.nx);
+    const long long tq = t / g.nx;
+    const int j0 = (int)(tq % nyb) * RY, k = (int)(tq / nyb);
     const float *__restrict__ phi = da.phi;
-    const float pc = phi[c];
-    const float fw = d_frac2(d_getf(g, phi, i - 1, j, k, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i, j - 1, k, da.phi_bg), pc)
-                     + d_frac2(d_getf(g, phi, i, j, k - 1, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i + 1, j, k, da.phi_bg), pc)
-                     + d_frac2(d_getf(g, phi, i, j + 1, k, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i, j, k + 1, da.phi_bg), pc);
-    const double denom = (double)(fw / 6) * da.vs3;
-    const bool with_density = fw > 0;
+    bool live[RY], with_density[RY];
+    float fw[RY], dens[RY];
+    double denom[RY], rden[RY];
+    bool any_live = false, any_walk = false;
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const int j = j0 + r;
+        live[r] = false; with_density[r] = false;
+        fw[r] = 0.f; dens[r] = 0.f; denom[r] = 1.0; rden[r] = 1.0;
+        if (j >= g.ny) continue;
+        const long long c = d_lid(g, i, j, k);
+        if (!(band[c] & 2)) {
+            if (P2G) { u[c] = 0.0; v[c] = 0.0; w[c] = 0.0; active[c] = 0; }
+            da.density[c] = 0.f;
+            continue;
+        }
+        live[r] = true;
+        any_live = true;
+        const float pc = phi[c];
+        fw[r] = d_frac2(d_getf(g, phi, i - 1, j, k, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i, j - 1, k, da.phi_bg), pc)
+                + d_frac2(d_getf(g, phi, i, j, k - 1, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i + 1, j, k, da.phi_bg), pc)
+                + d_frac2(d_getf(g, phi, i, j + 1, k, da.phi_bg), pc) + d_frac2(d_getf(g, phi, i, j, k + 1, da.phi_bg), pc);
+        denom[r] = (double)(fw[r] / 6) * da.vs3;
+        with_density[r] = fw[r] > 0;
+        if (with_density[r]) rden[r] = 1.0 / denom[r];
+        any_walk = any_walk || P2G || with_density[r];
+    }
+    if (!any_live) return;
     int nr = 0;
-    if (P2G || with_density) {
+    if (any_walk) {
         const int sxa = i > 0 ? 2 * i - 1 : 0, sxb = i < g.nx - 1 ? 2 * i + 2 : 2 * g.nx - 1;
         const int nx2 = 2 * g.nx;
 #pragma unroll
@@ -438,30 +463,47 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, const int32_t
             const int kk = k + dk;
             if (kk < 0 || kk >= g.nz) continue;
 #pragma unroll
-            for (int dj = -1; dj <= 1; ++dj) {
-                const int jj = j + dj;
+            for (int dj = -1; dj <= RY; ++dj) {
+                const int jj = j0 + dj;
                 if (jj < 0 || jj >= g.ny) continue;
                 const long long rowbase = ((long long)kk * g.ny + jj) * (4LL * nx2);
 #pragma unroll
                 for (int hz = (dk < 0 ? 1 : 0); hz <= (dk > 0 ? 0 : 1); ++hz) {
 #pragma unroll
-                    for (int hy = (dj < 0 ? 1 : 0); hy <= (dj > 0 ? 0 : 1); ++hy) {
+                    for (int hy = (dj < 0 ? 1 : 0); hy <= (dj >= RY ? 0 : 1); ++hy) {
+                        // half-cell row 2 dj + hy (relative to the column's first cell) lies in the support of cell r iff
+                        // 2 r - 1 <= 2 dj + hy <= 2 r + 2
+                        const int rel = 2 * dj + hy;
+                        unsigned feeds = 0;
+#pragma unroll
+                        for (int r = 0; r < RY; ++r)
+                            if (live[r] && rel >= 2 * r - 1 && rel <= 2 * r + 2) feeds |= 1u << r;
+                        if (!feeds) continue;
                         const int32_t *row = sub_start + rowbase + (long long)(hz * 2 + hy) * nx2;
                         const int32_t s0 = row[sxa], s1 = row[sxb + 1];
-                        if (s0 < s1) { runs[nr][tid] = make_int2(s0, s1); ++nr; }
+                        if (s0 < s1) {
+                            runs[nr][tid] = make_int2((int)((unsigned)s0 | ((feeds & 1u) << 31)), (int)((unsigned)s1 | ((feeds >> 1) << 31)));
+                            ++nr;
+                        }
                     }
                 }
             }
         }
     }
-    float dens = 0.f;
     const double eps = (double)10e-37f; // background of the weight grid (src/FluidSimulator.cpp:32,77)
-    double ws0 = eps, ws1 = eps, ws2 = eps, a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    const double cx = (double)(g.ox + i), cy = (double)(g.oy + j), cz = (double)(g.oz + k);
+    double ws0[RY], ws1[RY], ws2[RY], a0[RY], a1[RY], a2[RY], cy[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        ws0[r] = ws1[r] = ws2[r] = eps;
+        a0[r] = a1[r] = a2[r] = 0.0;
+        cy[r] = (double)(g.oy + j0 + r);
+    }
+    const double cx = (double)(g.ox + i), cz = (double)(g.oz + k);
     if (nr > 0) {
-        int r = 0;
+        int r_idx = 0;
         int2 cur = runs[0][tid];
-        int32_t s = cur.x, e = cur.y;
+        unsigned feeds = ((unsigned)cur.x >> 31) | (((unsigned)cur.y >> 31) << 1);
+        int32_t s = cur.x & 0x7fffffff, e = cur.y & 0x7fffffff;
         const double2 *rec = reinterpret_cast<const double2 *>(pm + s);
         double2 p0 = rec[0], p1 = rec[1]; // (x, y) (z, mass)
         double2 q0 = make_double2(0.0, 0.0), q1 = q0;
@@ -469,20 +511,22 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, const int32_t
             const double2 *vel = reinterpret_cast<const double2 *>(pv + s);
             q0 = vel[0]; q1 = vel[1]; // (vx, vy) (vz, -)
         }
-        bool live = true;
-        while (live) {
+        bool more = true;
+        while (more) {
             const double2 r0 = p0, r1 = p1, r2 = q0, r3 = q1;
+            const unsigned fd = feeds;
             // step to the next record of the flat sequence and request it
             ++s;
             if (s == e) {
-                ++r;
-                live = r < nr;
-                if (live) {
-                    cur = runs[r][tid];
-                    s = cur.x; e = cur.y;
+                ++r_idx;
+                more = r_idx < nr;
+                if (more) {
+                    cur = runs[r_idx][tid];
+                    feeds = ((unsigned)cur.x >> 31) | (((unsigned)cur.y >> 31) << 1);
+                    s = cur.x & 0x7fffffff; e = cur.y & 0x7fffffff;
                 }
             }
-            if (live) {
+            if (more) {
                 rec = reinterpret_cast<const double2 *>(pm + s);
                 p0 = rec[0]; p1 = rec[1];
                 if (P2G) {
@@ -490,36 +534,72 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, const int32_t
                     q0 = vel[0]; q1 = vel[1];
                 }
             }
-            const double d0 = r0.x - cx, d1 = r0.y - cy, d2 = r1.x - cz;
+            const double d0 = r0.x - cx, d2 = r1.x - cz;
             // inside the support the hat function is 1 - |x| (1 + x for a negative x is the same IEEE operation), and the
             // shifted argument x + 1/2 lies in [-1/2, 3/2], so only its upper cut-off needs a test
-            const double hx = d_hat_in(d0), hy = d_hat_in(d1), hz = d_hat_in(d2);
-            const double wgt = hx * hy * hz;
-            if (with_density && wgt > 0) {
-                const float mass = __int_as_float((int)(__double_as_longlong(r1.y) & 0xffffffffLL));
-                const double add = (double)0.f + wgt * (double)mass / denom;
-                dens = (float)((double)dens + add);
-            }
-            if (P2G) {
-                const float x0 = (float)hx, y0 = (float)hy, z0 = (float)hz;
-                const float x1 = (float)d_hat_up(d0 + 0.5), y1 = (float)d_hat_up(d1 + 0.5), z1 = (float)d_hat_up(d2 + 0.5);
-                const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
-                if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
-                    ws0 = ws0 + w0; ws1 = ws1 + w1; ws2 = ws2 + w2;
-                    a0 = a0 + w0 * r2.x; a1 = a1 + w1 * r2.y; a2 = a2 + w2 * r3.x;
+            const double hx = d_hat_in(d0), hz = d_hat_in(d2);
+            const float mass = __int_as_float((int)(__double_as_longlong(r1.y) & 0xffffffffLL));
+            const float x0 = (float)hx, z0 = (float)hz;
+            const float x1 = (float)d_hat_up(d0 + 0.5), z1 = (float)d_hat_up(d2 + 0.5);
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                if (RY > 1 && !((fd >> r) & 1u)) continue;
+                const double d1 = r0.y - cy[r];
+                const double hy = d_hat_in(d1);
+                const double wgt = hx * hy * hz;
+                if (with_density[r] && wgt > 0) {
+                    const double a = wgt * (double)mass;
+                    const double qa = a * rden[r];
+                    const double quot = fma(fma(-qa, denom[r], a), rden[r], qa); // = a / denom[r], correctly rounded
+                    const double add = (double)0.f + quot;
+                    dens[r] = (float)((double)dens[r] + add);
+                }
+                if (P2G) {
+                    const float y0 = (float)hy;
+                    const float y1 = (float)d_hat_up(d1 + 0.5);
+                    const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
+                    if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
+                        ws0[r] = ws0[r] + w0; ws1[r] = ws1[r] + w1; ws2[r] = ws2[r] + w2;
+                        a0[r] = a0[r] + w0 * r2.x; a1[r] = a1[r] + w1 * r2.y; a2[r] = a2[r] + w2 * r3.x;
+                    }
                 }
             }
         }
     }
-    if (P2G) {
-        u[c] = a0 / ws0;
-        v[c] = a1 / ws1;
-        w[c] = a2 / ws2;
-        active[c] = 1;
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        if (!live[r]) continue;
+        const long long c = d_lid(g, i, j0 + r, k);
+        if (P2G) {
+            u[c] = a0[r] / ws0[r];
+            v[c] = a1[r] / ws1[r];
+            w[c] = a2[r] / ws2[r];
+            active[c] = 1;
+        }
+        float dn = dens[r];
+        if (0 < fw[r] && fw[r] < 6) dn = dn > da.rest ? dn : da.rest;
+        da.density[c] = dn;
+        if ((double)dn > 1.5 * (double)da.rest) atomicAdd(da.n_over, 1);
     }
-    if (0 < fw && fw < 6) dens = dens > da.rest ? dens : da.rest;
-    da.density[c] = dens;
-    if ((double)dens > 1.5 * (double)da.rest) atomicAdd(da.n_over, 1);
+}
+
+// cells of a y-column per thread in the gathers: FLIP_GATHER_COLUMN=1|2 (tuning aid)
+static int gather_column() {
+    static const int v = [] { const char *e = getenv("FLIP_GATHER_COLUMN"); const int q = e ? atoi(e) : 2; return q == 1 ? 1 : 2; }();
+    return v;
+}
+template <bool P2G>
+static void launch_gather(flip_ctx *ctx, const DensityArgs &da) {
+    double *u = P2G ? ctx->vel[1][0] : nullptr, *v = P2G ? ctx->vel[1][1] : nullptr, *w = P2G ? ctx->vel[1][2] : nullptr;
+    uint8_t *act = P2G ? ctx->active : nullptr;
+    if (gather_column() == 2) {
+        const int nyb = (ctx->g.ny + 1) / 2;
+        k_gather<P2G, 2><<<flip_grid_blocks((long long)ctx->g.nx * nyb * ctx->g.nz), FLIP_BLOCK, 0, ctx->stream>>>(
+            flip_dims(ctx), nyb, ctx->sub_start, ctx->band, packed_pos(ctx), packed_vel(ctx), u, v, w, act, da);
+    } else {
+        k_gather<P2G, 1><<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->g.ny, ctx->sub_start, ctx->band,
+                                                                                  packed_pos(ctx), packed_vel(ctx), u, v, w, act, da);
+    }
 }
 
 static int ensure_records(flip_ctx *ctx) {
@@ -540,9 +620,7 @@ extern "C" int flip_p2g(flip_ctx *ctx) {
     DensityArgs da{ ctx->phi_fluid, ctx->density, ctx->d_counts + 2, ctx->g.phi_fluid_bg, ctx->g.rest_density,
                     pow((double)ctx->g.dx, 3) };
     FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
-    k_gather<true><<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->sub_start, ctx->band, packed_pos(ctx),
-                                                                            packed_vel(ctx), ctx->vel[1][0], ctx->vel[1][1], ctx->vel[1][2],
-                                                                            ctx->active, da);
+    launch_gather<true>(ctx, da);
     FLIP_LAUNCH_CHECK();
     ctx->density_valid = true;
     for (int a = 0; a < 3; ++a) std::swap(ctx->vel[0][a], ctx->vel[1][a]);
@@ -990,8 +1068,7 @@ extern "C" int flip_density(flip_ctx *ctx, int64_t *n_overdense) {
         DensityArgs da{ ctx->phi_fluid, ctx->density, ctx->d_counts + 2, ctx->g.phi_fluid_bg, ctx->g.rest_density,
                         pow((double)ctx->g.dx, 3) };
         FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 2, 0, 4, ctx->stream));
-        k_gather<false><<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->sub_start, ctx->band, packed_pos(ctx),
-                                                                                 packed_vel(ctx), nullptr, nullptr, nullptr, nullptr, da);
+        launch_gather<false>(ctx, da);
         FLIP_LAUNCH_CHECK();
         ctx->density_valid = true;
     }
