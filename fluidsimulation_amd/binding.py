@@ -61,7 +61,7 @@ EXPORTS = [
     "flip_binning_download", "flip_field_upload", "flip_field_download", "flip_field_bytes", "flip_p2g", "flip_g2p",
     "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_fluid_levelset_from_particles", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
     "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_velocity_max_static", "flip_index_cells", "flip_face_fractions",
-    "flip_density", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
+    "flip_density", "flip_redistribute_overdense", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
     "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_project_velocity",
     "flip_project_displacement", "flip_set_slab", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
     "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish", "flip_set_slab_overlap",
@@ -113,6 +113,7 @@ def load_library(path: str = LIB_PATH):
         "flip_index_cells": (C.c_int, [vp, P(i32)]),
         "flip_face_fractions": (C.c_int, [vp]),
         "flip_density": (C.c_int, [vp, P(i64)]),
+        "flip_redistribute_overdense": (C.c_int, [vp, C.c_uint32, P(i64), P(i64)]),
         "flip_solid_object_set": (C.c_int, [vp, vp, f32, vp, vp, vp]),
         "flip_solid_object_velocity": (C.c_int, [vp, P(f64)]),
         "flip_build_system": (C.c_int, [vp, C.c_int, f32]),
@@ -287,6 +288,12 @@ class FlipContext:
         n = C.c_int64(0)
         self._check(self.lib.flip_density(self.h, C.byref(n) if want_count else None))
         return n.value
+
+    def redistribute_overdense(self, seed: int):
+        """(cells touched, particles moved) by the re-seeding of over-dense cells (src/Functors.cpp:268-322)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.flip_redistribute_overdense(self.h, int(seed) & 0xffffffff, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_solid_object(self, phi_object, bg, com, minv, vel):
         if phi_object is None:

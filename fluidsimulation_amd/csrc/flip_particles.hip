@@ -1080,3 +1080,84 @@ extern "C" int flip_density(flip_ctx *ctx, int64_t *n_overdense) {
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Redistribution of the particles of over-dense cells (src/Functors.cpp:268-322): a cell whose density exceeds 1.5 rest
+// density has its n particles spread over the f^3 sub-cells of a lattice, f = the largest integer with f^3 <= n, in a
+// shuffled order, each at a uniform random offset inside its sub-cell.  The reference draws from a random_device-seeded
+// global generator inside a TBB loop, so it does not reproduce itself; here every draw is the stateless hash of
+// headers/util.h:259-266 (randhash) keyed on (seed, cell, draw number), and every density is the value computed before
+// any particle moved.  One thread per cell; the shuffled list lives in the cell's own slots of a scratch array.
+__device__ __forceinline__ uint32_t d_randhash(uint32_t seed) {
+    uint32_t i = (seed ^ 0xA3C59AC3u) * 2654435769u;
+    i ^= (i >> 16);
+    i *= 2654435769u;
+    i ^= (i >> 16);
+    i *= 2654435769u;
+    return i;
+}
+__device__ __forceinline__ double d_redist_uniform(uint32_t base, uint32_t q) {
+    const uint32_t hi = d_randhash(base + 0x10000000u + 2u * q) >> 5, lo = d_randhash(base + 0x10000000u + 2u * q + 1u) >> 6;
+    return ((double)hi * 67108864.0 + (double)lo) * (1.0 / 9007199254740992.0);
+}
+__global__ void k_redistribute(GridDims g, float rest, uint32_t seed, const float *__restrict__ density, const int32_t *__restrict__ cell_start,
+                               int32_t *__restrict__ list_scratch, double *__restrict__ px, double *__restrict__ py,
+                               double *__restrict__ pz, int32_t *__restrict__ counters) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.B) return;
+    if (!((double)density[c] > 1.5 * (double)rest)) return;
+    const int32_t s0 = cell_start[c], m = cell_start[c + 1] - s0;
+    if (m == 0) return;
+    int f = 1;
+    while ((long long)(f + 1) * (f + 1) * (f + 1) <= m) ++f;
+    const int32_t sub = f * f * f;
+    int32_t *list = list_scratch + s0; // sub <= m entries
+    for (int32_t a = 0; a < sub; ++a) list[a] = a;
+    const uint32_t base = d_randhash(d_randhash(seed) ^ (uint32_t)c);
+    for (int32_t a = sub - 1; a >= 1; --a) {
+        const int32_t b = (int32_t)(d_randhash(base + (uint32_t)a) % (uint32_t)(a + 1));
+        const int32_t t = list[a]; list[a] = list[b]; list[b] = t;
+    }
+    int i, j, k;
+    d_ijk(g, c, i, j, k);
+    const double cx = (double)(g.ox + i) - 0.5, cy = (double)(g.oy + j) - 0.5, cz = (double)(g.oz + k) - 0.5;
+    const double fd = (double)f;
+    for (int32_t q = 0; q < m; ++q) {
+        const int32_t idx = list[q % sub];
+        const int sx = idx / (f * f), sy = (idx / f) % f, sz = idx % f; // linearTo3d, headers/util.h:451-456
+        px[s0 + q] = (cx + (double)sx / fd) + d_redist_uniform(base, 3u * (uint32_t)q) / fd;
+        py[s0 + q] = (cy + (double)sy / fd) + d_redist_uniform(base, 3u * (uint32_t)q + 1u) / fd;
+        pz[s0 + q] = (cz + (double)sz / fd) + d_redist_uniform(base, 3u * (uint32_t)q + 2u) / fd;
+    }
+    atomicAdd(counters, 1);
+    atomicAdd(counters + 1, m);
+}
+
+extern "C" int flip_redistribute_overdense(flip_ctx *ctx, uint32_t seed, int64_t *n_cells, int64_t *n_particles) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(ctx->binned && ctx->slots_valid, "flip_redistribute_overdense: call flip_bin_particles first (the slots must describe the cells)");
+    FLIP_REQUIRE(ctx->density_valid, "flip_redistribute_overdense: call flip_p2g or flip_density first");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (ctx->n > 0) {
+        FLIP_CHECK(hipMemsetAsync(ctx->cell_fill, 0, 8, st)); // scratch of the sort, free between sorts: [0] cells, [1] particles
+        double **q = ctx->p[ctx->cur];
+        k_redistribute<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(flip_dims(ctx), ctx->g.rest_density, seed, ctx->density, ctx->cell_start,
+                                                                       ctx->slot_src, q[0], q[1], q[2], ctx->cell_fill);
+        FLIP_LAUNCH_CHECK();
+    }
+    int32_t h[2] = { 0, 0 };
+    if (ctx->n > 0) {
+        FLIP_CHECK(hipMemcpyAsync(h, ctx->cell_fill, 8, hipMemcpyDeviceToHost, st));
+        FLIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (n_cells) *n_cells = h[0];
+    if (n_particles) *n_particles = h[1];
+    if (h[1] > 0) {
+        // positions changed inside their cells: the packed copies and the half-cell order are stale, the cell ranges are not
+        ctx->binned = false;
+        ctx->prec_valid = false;
+        ctx->density_valid = false;
+    }
+    return 0;
+}

@@ -15,7 +15,7 @@ class FlipSubstep:
     def __init__(self, ctx: FlipContext, flip_pic_ratio: float = 0.95, tol: float = 1e-15, max_iter: int = 0,
                  precond: int = PRECOND_JACOBI, density_projection: bool = True, constrain: bool = False,
                  advect: bool = False, rigid_body: bool = False, levelset_radius: float | None = None,
-                 concurrent_solves: bool = False):
+                 concurrent_solves: bool = False, redistribute_seed: int | None = None):
         self.ctx = ctx
         # the density system does not depend on the divergence solve: both can be assembled first and solved side by side
         self.concurrent_solves = concurrent_solves and density_projection
@@ -26,6 +26,10 @@ class FlipSubstep:
         self.density_projection = density_projection   # DENSITY_CONSTRAINT_PPE, src/FluidSimulator.cpp:31
         self.constrain, self.advect, self.rigid_body = constrain, advect, rigid_body
         self.levelset_radius = levelset_radius   # world units; None: the fluid level set is an input
+        # re-seeding of over-dense cells (src/Functors.cpp:268-322) with draws keyed on (seed + substep number); None: off,
+        # as in every fixture (the reference's own draws are not reproducible)
+        self.redistribute_seed = redistribute_seed
+        self.substeps = 0
         self.info = {}
 
     def _constrain(self):
@@ -48,6 +52,9 @@ class FlipSubstep:
         c.index_cells()                           # :486  (weights of the previous substep)
         c.face_fractions()                        # :488
         c.density(want_count=False)               # :491
+        if self.redistribute_seed is not None:
+            c.redistribute_overdense(self.redistribute_seed + self.substeps)   # src/Functors.cpp:268-322, inside :491
+        self.substeps += 1
         info_den = None
         if self.concurrent_solves:
             info_div, info_den = c.solve_pair(dt, self.tol, self.max_iter, self.precond)   # :505 and :521

@@ -204,6 +204,14 @@ int flip_face_fractions(flip_ctx *ctx);
  * computes the field; this call only launches a kernel when particles, sort or level set changed since. */
 int flip_density(flip_ctx *ctx, int64_t *n_overdense);
 
+/* The side effect of DensityCalculator on the particles (src/Functors.cpp:268-322): the particles of every cell whose
+ * density exceeds 1.5 rest density are spread over a shuffled lattice of sub-cells of that cell, each at a uniform random
+ * offset.  The reference draws from a random_device-seeded generator shared by its TBB threads and does not reproduce
+ * itself; every draw here is headers/util.h's randhash of (seed, cell, draw number), so equal inputs and seed give equal
+ * positions.  Call after flip_p2g / flip_density of the same substep; n_cells / n_particles (may be NULL) receive how
+ * many cells and particles were touched.  Off unless called: the reference's own results differ run to run here. */
+int flip_redistribute_overdense(flip_ctx *ctx, uint32_t seed, int64_t *n_cells, int64_t *n_particles);
+
 /* Attach (phi_object != NULL) or detach the rigid body that is strongly coupled in the
  * divergence solve: SolidObject (headers/SolidObject.h:9-62).  com = centre of mass in index
  * space, minv = diagonal of SolidObject::massMatrixInverse, vel = combinedVelocityVector. */

@@ -87,6 +87,9 @@ class Oracle:
         L.orc_combine_weights.argtypes = [i64, vp, vp]
         L.orc_index_cells.restype = i32; L.orc_index_cells.argtypes = [G, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_density.restype = i64; L.orc_density.argtypes = [G, i64, vp, vp, vp, vp, vp, vp, f32, vp]
+        L.orc_advect_particles.argtypes = [G, i64, vp, vp, vp, vp, vp, vp, f32, f32]
+        L.orc_fluid_levelset.argtypes = [G, i64, vp, vp, vp, vp, f32, f32, vp]
+        L.orc_redistribute.restype = i64; L.orc_redistribute.argtypes = [G, i64, vp, vp, vp, vp, f32, C.c_uint32, C.POINTER(i64)]
         L.orc_build_system.argtypes = [G, C.c_int, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_stencil_to_csr.restype = i64; L.orc_stencil_to_csr.argtypes = [G, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_build_J.argtypes = [G, vp, vp, vp, vp, vp, i32, vp]
@@ -188,6 +191,35 @@ class Oracle:
         n_over = self.lib.orc_density(C.byref(self.g), pos.shape[0], _ptr(pos), _ptr(mass), _ptr(cell_start), _ptr(perm),
                                       _ptr(band2), _ptr(phi_fluid), self.rho, _ptr(d))
         return d, n_over
+
+    def advect_particles(self, pos, uvw, phi_solid, dt, phi_object=None, phi_object_bg=0.0):
+        """RK3 advection through the staggered field + push-out of the solids (src/FluidDomain.cpp:63-75)."""
+        out = np.ascontiguousarray(pos, dtype=np.float64).copy()
+        u, v, w = (np.ascontiguousarray(a, dtype=np.float64) for a in uvw)
+        po = None if phi_object is None else np.ascontiguousarray(phi_object, dtype=np.float32)
+        self.lib.orc_advect_particles(C.byref(self.g), out.shape[0], _ptr(out), _ptr(u), _ptr(v), _ptr(w),
+                                      _ptr(np.ascontiguousarray(phi_solid, dtype=np.float32)), _ptr(po), np.float32(phi_object_bg),
+                                      np.float32(dt))
+        return out
+
+    def fluid_levelset(self, pos, cell_start, perm, phi_solid, radius_world, half_width_voxels=3.0):
+        """Union of the particles' balls merged with the solid (src/FluidDomain.cpp:50-61)."""
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        out = self._f32()
+        self.lib.orc_fluid_levelset(C.byref(self.g), pos.shape[0], _ptr(pos), _ptr(cell_start), _ptr(perm),
+                                    _ptr(np.ascontiguousarray(phi_solid, dtype=np.float32)), np.float32(radius_world),
+                                    np.float32(half_width_voxels), _ptr(out))
+        return out
+
+    def redistribute(self, pos, cell_start, perm, density, seed):
+        """Re-seeds the particles of every cell above 1.5 rest density (src/Functors.cpp:268-322, hash-driven); returns
+        (new positions, cells touched, particles moved)."""
+        out = np.ascontiguousarray(pos, dtype=np.float64).copy()
+        moved = C.c_int64(0)
+        cells = self.lib.orc_redistribute(C.byref(self.g), out.shape[0], _ptr(out), _ptr(cell_start), _ptr(perm),
+                                          _ptr(np.ascontiguousarray(density, dtype=np.float32)), self.rho, int(seed) & 0xffffffff,
+                                          C.byref(moved))
+        return out, int(cells), int(moved.value)
 
     def build_system(self, kind, dt, label, phi_fluid, phi_solid, w, uvw=None, density=None):
         off = np.zeros((6,) + self.shape, dtype=np.float64)

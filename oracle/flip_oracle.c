@@ -495,9 +495,9 @@ ORC_EXPORT int32_t orc_index_cells(const orc_grid *g, const uint8_t *pmask1, con
 /* ------------------------------------------------------------------------------------ */
 /* Density: src/FluidSimulator.cpp:625-652 + src/Functors.cpp:216-266.                  */
 /* band2 = particle cells dilated 2.  vs3 = pow((double)dx, 3).  The redistribution of   */
-/* over-dense cells (Functors.cpp:277-322) draws from a random_device-seeded global RNG  */
-/* and is not restated; n_over returns how many cells exceed 1.5*rest_density so that a  */
-/* harness can tell whether the reference would have redistributed.                      */
+/* over-dense cells (Functors.cpp:277-322) is restated separately (orc_redistribute);    */
+/* n_over returns how many cells exceed 1.5*rest_density so that a                        */
+/* harness can tell whether the reference would have redistributed (orc_redistribute).    */
 ORC_EXPORT int64_t orc_density(const orc_grid *g, int64_t n, const double *pos, const float *mass,
                                const int32_t *cell_start, const int32_t *perm, const uint8_t *band2,
                                const float *phi, float rest_density, float *density) {
@@ -549,6 +549,72 @@ ORC_EXPORT int64_t orc_density(const orc_grid *g, int64_t n, const double *pos, 
     free(buf);
     }
     return n_over;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Redistribution of the particles of over-dense cells: src/Functors.cpp:268-322.  The     */
+/* reference draws from a std::random_device-seeded global mt19937 inside a TBB loop        */
+/* (src/util.cpp:5), so not even two runs of it agree; this restatement keeps the algorithm */
+/* and replaces the generator by the stateless hash of headers/util.h:259-266 (randhash),   */
+/* keyed on (seed, cell, draw number), so that the result depends on nothing but its inputs */
+/* (parity unpinned, necessarily).  Per cell whose density exceeds 1.5 rest density:        */
+/*   n particles of the cell (:269-272, :285; the atlas box [c-1/2, c+1/2] is restated as   */
+/*   "binned in cell c"), f = the largest integer with f^3 <= n (:288; floor(pow(n, 1/3.))  */
+/*   lands one lower at some perfect cubes depending on the C library), a shuffled list of  */
+/*   the f^3 sub-cells (:292-296; std::shuffle restated as Fisher-Yates from the top), and  */
+/*   the m-th particle in slot order goes to sub-cell list[m % f^3] at a uniform random      */
+/*   offset: corner + (i,j,k)/f + U/f with linearTo3d's index order (:305-315).             */
+/* All densities are taken from the field as computed before any particle moved.           */
+static inline uint32_t randhash_u(uint32_t seed) { /* headers/util.h:259-266 */
+    uint32_t i = (seed ^ 0xA3C59AC3u) * 2654435769u;
+    i ^= (i >> 16);
+    i *= 2654435769u;
+    i ^= (i >> 16);
+    i *= 2654435769u;
+    return i;
+}
+static inline uint32_t redist_base(uint32_t seed, int64_t cell) { return randhash_u(randhash_u(seed) ^ (uint32_t)cell); }
+static inline double redist_uniform(uint32_t base, uint32_t q) { /* 53-bit uniform in [0, 1) from two hashes */
+    const uint32_t hi = randhash_u(base + 0x10000000u + 2u * q) >> 5, lo = randhash_u(base + 0x10000000u + 2u * q + 1u) >> 6;
+    return ((double)hi * 67108864.0 + (double)lo) * (1.0 / 9007199254740992.0);
+}
+ORC_EXPORT int64_t orc_redistribute(const orc_grid *g, int64_t n, double *pos, const int32_t *cell_start, const int32_t *perm,
+                                    const float *density, float rest_density, uint32_t seed, int64_t *n_moved) {
+    (void)n;
+    const int64_t B = ncell(g);
+    int64_t cells = 0, moved = 0;
+    int32_t *list = NULL;
+    int32_t cap = 0;
+    for (int64_t c = 0; c < B; ++c) {
+        if (!((double)density[c] > 1.5 * (double)rest_density)) continue;
+        const int32_t s0 = cell_start[c], m = cell_start[c + 1] - s0;
+        if (m == 0) continue;
+        int f = 1;
+        while ((int64_t)(f + 1) * (f + 1) * (f + 1) <= m) ++f;
+        const int32_t sub = f * f * f;
+        if (sub > cap) { cap = sub; list = (int32_t *)realloc(list, (size_t)cap * sizeof(int32_t)); }
+        for (int32_t a = 0; a < sub; ++a) list[a] = a;
+        const uint32_t base = redist_base(seed, c);
+        for (int32_t a = sub - 1; a >= 1; --a) {
+            const int32_t b = (int32_t)(randhash_u(base + (uint32_t)a) % (uint32_t)(a + 1));
+            const int32_t t = list[a]; list[a] = list[b]; list[b] = t;
+        }
+        const int k = (int)(c / ((int64_t)g->nx * g->ny)), j = (int)((c / g->nx) % g->ny), i = (int)(c % g->nx);
+        const double corner[3] = { (double)(g->ox + i) - 0.5, (double)(g->oy + j) - 0.5, (double)(g->oz + k) - 0.5 };
+        for (int32_t q = 0; q < m; ++q) {
+            const int32_t idx = list[q % sub];
+            /* linearTo3d(idx, f, f, i, j, k): headers/util.h:451-456 */
+            const int sc[3] = { idx / (f * f), (idx / f) % f, idx % f };
+            const int64_t p = perm[s0 + q];
+            for (int a = 0; a < 3; ++a)
+                pos[3 * p + a] = (corner[a] + (double)sc[a] / (double)f) + redist_uniform(base, 3u * (uint32_t)q + (uint32_t)a) / (double)f;
+        }
+        ++cells;
+        moved += m;
+    }
+    free(list);
+    if (n_moved) *n_moved = moved;
+    return cells;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1241,5 +1307,116 @@ ORC_EXPORT void orc_constrain_velocity(const orc_grid *g, const float *phi, floa
                 ou[c] = wu[c] == 1.f ? constrained_component(g, phi, phi_bg, u, v, w, i, j, k, 0, has_obj, vel_trans, vel_ang) : u[c];
                 ov[c] = wv[c] == 1.f ? constrained_component(g, phi, phi_bg, u, v, w, i, j, k, 1, has_obj, vel_trans, vel_ang) : v[c];
                 ow[c] = ww[c] == 1.f ? constrained_component(g, phi, phi_bg, u, v, w, i, j, k, 2, has_obj, vel_trans, vel_ang) : w[c];
+            }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Particle advection: src/FluidDomain.cpp:63-75 + src/ParticleSet.cpp:18-45.  The        */
+/* reference calls OpenVDB (tools::PointAdvect order 3, tools::cpt + BoxSampler); neither */
+/* is available, so this restates their published algorithms (parity unpinned):           */
+/*   VelocityIntegrator::rungeKutta<3>: V0 = v(P), V1 = v(P + dt/2 V0),                   */
+/*   V2 = v(P + dt (2 V1 - V0)), P += dt (V0 + 4 V1 + V2) / 6, velocities sampled with    */
+/*   the staggered box sampler, positions kept in index space (world = dx (index + 1/2)); */
+/*   a particle that ends where the combined solid level set (container, csgUnion = min   */
+/*   with the rigid body) is <= 0 goes to the closest point of the surface; for a signed  */
+/*   distance that point is P - phi grad(phi) / |grad(phi)|, the gradient taken by        */
+/*   central differences of the sampled level set half a cell either side.                */
+static float box_sample_f(const orc_grid *g, const float *f, float bg, double x, double y, double z) {
+    const double fx = floor(x), fy = floor(y), fz = floor(z);
+    const int i = (int)fx - g->ox, j = (int)fy - g->oy, k = (int)fz - g->oz;
+    const double tu = x - fx, tv = y - fy, tw = z - fz;
+    float d[2][2][2];
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            for (int c = 0; c < 2; ++c) d[a][b][c] = getf(g, f, i + a, j + b, k + c, bg);
+    return lerp_f(lerp_f(lerp_f(d[0][0][0], d[0][0][1], tw), lerp_f(d[0][1][0], d[0][1][1], tw), tv),
+                  lerp_f(lerp_f(d[1][0][0], d[1][0][1], tw), lerp_f(d[1][1][0], d[1][1][1], tw), tv), tu);
+}
+static float solid_sample(const orc_grid *g, const float *phi_s, float bg_s, const float *phi_o, float bg_o, double x, double y,
+                          double z) {
+    float v = box_sample_f(g, phi_s, bg_s, x, y, z);
+    if (phi_o) {
+        const float o = box_sample_f(g, phi_o, bg_o, x, y, z);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+ORC_EXPORT void orc_advect_particles(const orc_grid *g, int64_t n, double *pos, const double *u, const double *v, const double *w,
+                                     const float *phi_solid, const float *phi_object, float phi_object_bg, float dt) {
+    const double inv_dx = 1.0 / (double)g->dx;
+    const double dt_over_dx = (double)dt * inv_dx;
+    const float bg_s = g->phi_solid_bg;
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < n; ++p) {
+        const double x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+        double a[3], b[3], c[3];
+        const double P0[3] = { x, y, z };
+        staggered_sample(g, u, v, w, P0, a);
+        const double h = 0.5 * dt_over_dx;
+        const double P1[3] = { x + h * a[0], y + h * a[1], z + h * a[2] };
+        staggered_sample(g, u, v, w, P1, b);
+        const double P2[3] = { x + dt_over_dx * (2.0 * b[0] - a[0]), y + dt_over_dx * (2.0 * b[1] - a[1]),
+                               z + dt_over_dx * (2.0 * b[2] - a[2]) };
+        staggered_sample(g, u, v, w, P2, c);
+        double nx = x + dt_over_dx * (a[0] + 4.0 * b[0] + c[0]) / 6.0;
+        double ny = y + dt_over_dx * (a[1] + 4.0 * b[1] + c[1]) / 6.0;
+        double nz = z + dt_over_dx * (a[2] + 4.0 * b[2] + c[2]) / 6.0;
+        const float phi = solid_sample(g, phi_solid, bg_s, phi_object, phi_object_bg, nx, ny, nz);
+        if (phi <= 0.f) {
+            const double gx = (double)solid_sample(g, phi_solid, bg_s, phi_object, phi_object_bg, nx + 0.5, ny, nz)
+                              - (double)solid_sample(g, phi_solid, bg_s, phi_object, phi_object_bg, nx - 0.5, ny, nz);
+            const double gy = (double)solid_sample(g, phi_solid, bg_s, phi_object, phi_object_bg, nx, ny + 0.5, nz)
+                              - (double)solid_sample(g, phi_solid, bg_s, phi_object, phi_object_bg, nx, ny - 0.5, nz);
+            const double gz = (double)solid_sample(g, phi_solid, bg_s, phi_object, phi_object_bg, nx, ny, nz + 0.5)
+                              - (double)solid_sample(g, phi_solid, bg_s, phi_object, phi_object_bg, nx, ny, nz - 0.5);
+            const double len = sqrt(gx * gx + gy * gy + gz * gz);
+            if (len > 0.0) {
+                const double d = -(double)phi * inv_dx / len;
+                nx += d * gx; ny += d * gy; nz += d * gz;
+            }
+        }
+        pos[3 * p] = nx; pos[3 * p + 1] = ny; pos[3 * p + 2] = nz;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Fluid level set from the marker particles: src/FluidDomain.cpp:50-61 with               */
+/* LevelSet::unionOfBalls (src/LevelSet.cpp:17-23) and IntersectSolidFluidLevelSets       */
+/* (headers/LevelSet.h:83-96).  OpenVDB's ParticlesToLevelSet rasterises the spheres      */
+/* onto the narrow band; restated as the exact union of balls (parity unpinned):          */
+/* phi(c) = min_p |c - p| - radius in index units, clipped to +-half_width voxels, times  */
+/* dx, as float; then, where the solid level set is <= 0, max(phi, -phi_solid).  A cell   */
+/* with no particle within radius + half_width keeps +half_width dx.                      */
+ORC_EXPORT void orc_fluid_levelset(const orc_grid *g, int64_t n, const double *pos, const int32_t *cell_start, const int32_t *perm,
+                                   const float *phi_solid, float radius_world, float half_width_voxels, float *phi_fluid) {
+    (void)n;
+    const double radius = (double)radius_world / (double)g->dx, half_width = (double)half_width_voxels;
+    const int reach = (int)ceil(radius + half_width);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int k = 0; k < g->nz; ++k)
+        for (int j = 0; j < g->ny; ++j)
+            for (int i = 0; i < g->nx; ++i) {
+                const double cx = (double)(g->ox + i), cy = (double)(g->oy + j), cz = (double)(g->oz + k);
+                double best2 = 1e300;
+                for (int kk = k - reach; kk <= k + reach; ++kk)
+                    for (int jj = j - reach; jj <= j + reach; ++jj) {
+                        if (kk < 0 || kk >= g->nz || jj < 0 || jj >= g->ny) continue;
+                        const int xa = i - reach > 0 ? i - reach : 0, xb = i + reach < g->nx - 1 ? i + reach : g->nx - 1;
+                        const int64_t row = (int64_t)g->nx * ((int64_t)jj + (int64_t)g->ny * kk);
+                        for (int32_t s = cell_start[row + xa]; s < cell_start[row + xb + 1]; ++s) {
+                            const int64_t p = perm[s];
+                            const double dx = cx - pos[3 * p], dy = cy - pos[3 * p + 1], dz = cz - pos[3 * p + 2];
+                            const double d2 = dx * dx + dy * dy + dz * dz;
+                            if (d2 < best2) best2 = d2;
+                        }
+                    }
+                const int64_t c = lid(g, i, j, k);
+                double d = half_width;
+                if (best2 < 1e299) d = sqrt(best2) - radius;
+                d = d < -half_width ? -half_width : (d > half_width ? half_width : d);
+                float f = (float)(d * (double)g->dx);
+                const float ps = phi_solid[c];
+                if (ps <= 0) f = f > -ps ? f : -ps;
+                phi_fluid[c] = f;
             }
 }

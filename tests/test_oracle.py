@@ -314,3 +314,28 @@ def test_constrain_velocity_removes_the_wall_normal_component():
         x, y, z = ox + i, oy + j, oz + k
         if lo[0] + 2 < x < hi[0] - 2 and lo[2] + 2 < z < hi[2] - 2 and y < lo[1] - 1:
             assert abs(out[0][k, j, i] - 0.7) < 1e-12
+
+
+def test_redistribution_restatement_properties():
+    """orc_redistribute (src/Functors.cpp:268-322 with hash-driven draws): deterministic, keeps particles in their
+    cells, touches only over-dense cells, fills every sub-cell of the lattice."""
+    from fluidsimulation_amd import scenes
+    from oracle import Oracle
+    sc = scenes.cube_drop(12, ppc=27, seed=4, exact_levelset=False)
+    o = Oracle(sc.desc())
+    cell_id, cell_start, perm, _ = o.bin_particles(sc.pos)
+    band2 = o.particle_mask(cell_start, 2)
+    dens, n_over = o.density(sc.pos, sc.mass * 3.0, cell_start, perm, band2, sc.phi_fluid)
+    a, cells, moved = o.redistribute(sc.pos, cell_start, perm, dens, seed=7)
+    b, _, _ = o.redistribute(sc.pos, cell_start, perm, dens, seed=7)
+    c, _, _ = o.redistribute(sc.pos, cell_start, perm, dens, seed=8)
+    assert cells > 0 and np.array_equal(a, b) and not np.array_equal(a, c)
+    over = (dens.ravel().astype(np.float64) > 1.5 * 1000.0)
+    changed = np.any(a != sc.pos, axis=1)
+    assert np.all(over[cell_id[changed]]) and changed.sum() == moved
+    assert np.array_equal(o.bin_particles(a)[0], cell_id)
+    # not over-dense anywhere: nothing moves
+    d0, n0 = o.density(sc.pos, sc.mass * 0.5, cell_start, perm, band2, sc.phi_fluid)
+    same, cells0, moved0 = o.redistribute(sc.pos, cell_start, perm, d0, seed=7)
+    if n0 == 0:
+        assert cells0 == 0 and moved0 == 0 and np.array_equal(same, sc.pos)
