@@ -29,6 +29,7 @@ public:
     void uploadFloat(int field, const flipvdb::FloatGrid &grid);
     flipvdb::FloatGrid::Ptr downloadFloat(int field, float background);
     flipvdb::Vec3dGrid::Ptr downloadVec3d(int field_x);
+    void uploadVec3d(int field_x, const flipvdb::Vec3dGrid &grid);
     flipvdb::MaskGrid::Ptr downloadMask(int field);
 
 private:

@@ -1,9 +1,10 @@
 // MacGrid.h -- headers/MacGrid.h:30-339 with the buffers resident on the device.
 //
 // Getters return a dense host snapshot of the device buffer (a download), where the reference returns the
-// live OpenVDB tree; buffer operations (previous / difference buffers) run on the device.  The reference's
-// per-voxel accessor setters (setVel*, addToVelInterpolated, ...) write single voxels of a host tree and
-// are used only by its dead Eulerian code path; they have no device-resident meaning and are not kept.
+// live OpenVDB tree; buffer operations (previous / difference buffers) run on the device.  The per-voxel
+// accessor setters (headers/MacGrid.h:96-306) write into the snapshot velFront() handed out; a snapshot that
+// was written to is kept, handed out again by velFront(), and uploaded by push(), which
+// FluidSimulator::advance_flip_pic calls before it touches the device.
 #pragma once
 
 #include "flipvdb.h"
@@ -42,6 +43,30 @@ public:
 
     inline float voxelSize() { return _voxel_size; };
 
+    // ---- per-voxel setters, headers/MacGrid.h:91-306 (same names, argument order and meaning) ----
+    using Accessor = flipvdb::Vec3dGrid::Accessor;
+    inline flipvdb::Vec3d velHalfIndexed(Accessor &accessor, flipvdb::Coord coord) const { return accessor.getValue(coord); }
+    inline flipvdb::Vec3d velHalfIndexed(Accessor &accessor, int k, int j, int i) const { return accessor.getValue(flipvdb::Coord(k, j, i)); }
+    void setVelHalfIndexed(Accessor &accessor, flipvdb::Coord coord, flipvdb::Vec3d vel);
+    void setVelHalfIndexed(Accessor &accessor, int k, int j, int i, flipvdb::Vec3d vel);
+    void setVelOneDimHalfIndexed(Accessor &accessor, flipvdb::Coord coord, double vel, int idx);
+    void setVelOneDimHalfIndexed(Accessor &accessor, int k, int j, int i, double vel, int idx);
+    // the 2x2x2 block of voxels whose low corner is the coordinate
+    void setVel(Accessor &accessor, flipvdb::Coord coord, flipvdb::Vec3d vel);
+    void setVel(Accessor &accessor, int k, int j, int i, flipvdb::Vec3d vel);
+    void setVelX(Accessor &accessor, flipvdb::Coord coord, double vel);
+    void setVelX(Accessor &accessor, int k, int j, int i, double vel);
+    void setVelY(Accessor &accessor, flipvdb::Coord coord, double vel);
+    void setVelY(Accessor &accessor, int k, int j, int i, double vel);
+    void setVelZ(Accessor &accessor, flipvdb::Coord coord, double vel);
+    void setVelZ(Accessor &accessor, int k, int j, int i, double vel);
+    // trilinear spreading of a value given at a world-space point onto the eight voxels around it
+    void addToVelInterpolated(Accessor &accessor, float x, float y, float z, flipvdb::Vec3d value);
+    void setVelInterpolated(Accessor &accessor, float x, float y, float z, flipvdb::Vec3d value);
+
+    // uploads the velFront() snapshot if a setter wrote to it since it was handed out
+    void push();
+
     void attach(std::shared_ptr<FlipDevice> device) { _device = device; }
     bool attached() const { return (bool)_device; }
 
@@ -49,4 +74,5 @@ private:
     flipvdb::Transform::Ptr _i2w_transform;
     float _voxel_size;
     std::shared_ptr<FlipDevice> _device;
+    flipvdb::Vec3dGrid::Ptr _front_snapshot;
 };

@@ -50,6 +50,10 @@ public:
     // headers/ParticleSet.h:55-56; the velocity and closest-point grids live on the device, so the call
     // takes only the time step (FluidDomain::advectParticles passes it through).
     void advectAndEnsureOutsideObstacles(float dt);
+    // The reference's signature (src/ParticleSet.cpp:18-19).  The three grids describe state the device already holds
+    // (velFront, the closest-point transform of the solids, their union), so they are accepted and not read.
+    void advectAndEnsureOutsideObstacles(flipvdb::Vec3dGrid::Ptr vel_grid, flipvdb::Vec3fGrid::Ptr cpt_grid, LevelSet &solid_level_set,
+                                         float dt);
 
     inline void addParticle(const Particle &p) {
         pull();

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdint>
 #include <memory>
+#include <string>
 #include <vector>
 
 namespace flipvdb {
@@ -95,12 +96,45 @@ private:
     Vec3d _t;
 };
 
+// What openvdb::GridBase is to main.cpp:117-119,175-181: a common base so that grids of any value type can sit in
+// one GridPtrVec.
+class GridBase {
+public:
+    using Ptr = std::shared_ptr<GridBase>;
+    virtual ~GridBase() {}
+    virtual const char *valueTypeName() const = 0;
+    virtual int64_t valueBytes() const = 0;
+    virtual const void *rawBytes() const = 0;
+    virtual CoordBBox gridBox() const = 0;
+};
+using GridPtrVec = std::vector<GridBase::Ptr>;
+template <class T> struct GridTypeName { static const char *name() { return "bytes"; } };
+template <> struct GridTypeName<float> { static const char *name() { return "float"; } };
+template <> struct GridTypeName<int32_t> { static const char *name() { return "int32"; } };
+
 // Dense grid over an inclusive box; x fastest: id = (i-ox) + nx*((j-oy) + ny*(k-oz)), the device layout.
 template <class T>
-class DenseGrid {
+class DenseGrid : public GridBase {
 public:
     using Ptr = std::shared_ptr<DenseGrid<T>>;
     using ValueType = T;
+    // Stands for openvdb::Grid::Accessor (headers/MacGrid.h:33): reads return the background outside the box, writes
+    // land in the grid and mark it edited (the owner of a device-backed snapshot uploads it before the next step).
+    class Accessor {
+    public:
+        explicit Accessor(DenseGrid *g): _g(g) {}
+        const T &getValue(const Coord &c) const { return _g->getValue(c); }
+        void setValue(const Coord &c, const T &v) { _g->setValue(c, v); _g->_edited = true; }
+    private:
+        DenseGrid *_g;
+    };
+    Accessor getAccessor() { return Accessor(this); }
+    bool edited() const { return _edited; }
+    void clearEdited() { _edited = false; }
+    const char *valueTypeName() const override { return GridTypeName<T>::name(); }
+    int64_t valueBytes() const override { return (int64_t)sizeof(T); }
+    const void *rawBytes() const override { return _data.data(); }
+    CoordBBox gridBox() const override { return _box; }
     static Ptr create(const CoordBBox &box, const T &background) { return Ptr(new DenseGrid(box, background)); }
     Ptr deepCopy() const { return Ptr(new DenseGrid(*this)); }
 
@@ -127,12 +161,14 @@ private:
     T _bg;
     std::vector<T> _data;
     Transform::Ptr _xform;
+    bool _edited = false;
 };
 
 using FloatGrid = DenseGrid<float>;
 using Vec3dGrid = DenseGrid<Vec3d>;
 using MaskGrid = DenseGrid<uint8_t>;
 using Int32Grid = DenseGrid<int32_t>;
+using Vec3fGrid = Vec3dGrid; // Vec3f is Vec3d here
 
 // Trilinear sample in index space (openvdb::tools::BoxSampler): z, then y, then x, each a + (b - a) * t.
 float sampleBox(const FloatGrid &grid, const Vec3d &index_point);
@@ -147,5 +183,55 @@ FloatGrid::Ptr createLevelSetSphere(float radius, const Vec3d &center, float vox
 // openvdb::tools::createLevelSetCube: a cube of edge `scale` centred at `center` (world units).
 FloatGrid::Ptr createLevelSetCube(float scale, const Vec3d &center, float voxel_size, const Transform &xform,
                                   float half_width = 3.0f);
+
+// openvdb::tools::csgUnionCopy (main.cpp:178-180) on signed distances: the minimum, over the union of the two boxes.
+FloatGrid::Ptr csgUnionCopy(const FloatGrid &a, const FloatGrid &b);
+
+inline void initialize() {} // openvdb::initialize (main.cpp:103): nothing to register
+
+// ---- the nested names main.cpp and the reference's public headers spell (openvdb::math::, ::tools::, ::io::) ----
+namespace math {
+using Transform = flipvdb::Transform;
+using Coord = flipvdb::Coord;
+using CoordBBox = flipvdb::CoordBBox;
+}
+namespace tools {
+// createLevelSetBox<GridType, VecType>(bbox, transform, halfWidth): main.cpp:122-125
+template <class GridT, class VecT>
+typename GridT::Ptr createLevelSetBox(const BBoxd &bbox, const flipvdb::Transform &xform, double half_width = 3.0) {
+    return flipvdb::createLevelSetBox(bbox, xform, half_width);
+}
+// createLevelSetCube<GridType>(scale, centre, voxelSize, halfWidth): main.cpp:83-84.  As in OpenVDB the grid is built
+// on a plain linear transform of that voxel size (voxel (i,j,k) at world voxelSize * (i,j,k)); a later setTransform
+// re-interprets the same voxels.
+template <class GridT>
+typename GridT::Ptr createLevelSetCube(float scale, const Vec3d &center, float voxel_size, float half_width = 3.0f) {
+    auto plain = flipvdb::Transform::createLinearTransform(voxel_size);
+    auto grid = flipvdb::createLevelSetCube(scale, center, voxel_size, *plain, half_width);
+    grid->setTransform(plain);
+    return grid;
+}
+template <class GridT>
+typename GridT::Ptr createLevelSetSphere(float radius, const Vec3d &center, float voxel_size, float half_width = 3.0f) {
+    auto plain = flipvdb::Transform::createLinearTransform(voxel_size);
+    auto grid = flipvdb::createLevelSetSphere(radius, center, voxel_size, half_width, *plain);
+    grid->setTransform(plain);
+    return grid;
+}
+inline FloatGrid::Ptr csgUnionCopy(const FloatGrid &a, const FloatGrid &b) { return flipvdb::csgUnionCopy(a, b); }
+}
+namespace io {
+// openvdb::io::File (main.cpp:111-113,193-199).  The .vdb container format is OpenVDB's own and not reproduced: write()
+// stores every grid as a dense little-endian block behind a one-line text header (value type, box, voxel size), which
+// is enough to look at a result and to compare two runs.
+class File {
+public:
+    explicit File(const std::string &name): _name(name) {}
+    void write(const GridPtrVec &grids);
+    void close() {}
+private:
+    std::string _name;
+};
+}
 
 } // namespace flipvdb

@@ -47,6 +47,17 @@ Vec3dGrid::Ptr FlipDevice::downloadVec3d(int field_x) {
     return g;
 }
 
+void FlipDevice::uploadVec3d(int field_x, const Vec3dGrid &grid) {
+    std::vector<double> comp((size_t)cells());
+    for (int c = 0; c < 3; ++c) {
+        size_t q = 0;
+        for (int k = _box.mn[2]; k <= _box.mx[2]; ++k)
+            for (int j = _box.mn[1]; j <= _box.mx[1]; ++j)
+                for (int i = _box.mn[0]; i <= _box.mx[0]; ++i) comp[q++] = grid.getValue(Coord(i, j, k))[c];
+        check(flip_field_upload(_ctx, field_x + c, comp.data()), "flip_field_upload");
+    }
+}
+
 MaskGrid::Ptr FlipDevice::downloadMask(int field) {
     auto g = MaskGrid::create(_box, 0);
     check(flip_field_download(_ctx, field, g->raw()), "flip_field_download");

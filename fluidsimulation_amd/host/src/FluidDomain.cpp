@@ -1,5 +1,7 @@
 #include "FluidDomain.h"
 
+#include <stdexcept>
+
 using namespace flipvdb;
 
 const float FluidDomain::density { 1000.f };
@@ -26,7 +28,13 @@ void FluidDomain::addFluidSource(std::shared_ptr<FluidSource> fluid_source) { _f
 void FluidDomain::removeFluidSource(int i) {
     if ((int)_fluid_sources.size() >= i + 1) _fluid_sources.erase(_fluid_sources.begin() + i);
 }
-void FluidDomain::addSolidObj(std::shared_ptr<SolidObject> solid_obj) { _solid_objs.push_back(solid_obj); }
+void FluidDomain::addSolidObj(std::shared_ptr<SolidObject> solid_obj) {
+    // the device couples ONE rigid body in the divergence solve (flip_solid_object_set); a second one would keep moving
+    // while being left out of the solve and of the velocity constraints, so it is refused here
+    if (!_solid_objs.empty())
+        throw std::runtime_error("FluidDomain::addSolidObj: the device path supports one rigid body per domain");
+    _solid_objs.push_back(solid_obj);
+}
 void FluidDomain::removeSolidObj(int i) {
     if ((int)_solid_objs.size() >= i + 1) _solid_objs.erase(_solid_objs.begin() + i);
 }

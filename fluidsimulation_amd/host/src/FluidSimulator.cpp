@@ -36,6 +36,7 @@ void FluidSimulator::advance_flip_pic(FluidDomain &domain, float t_frame, float 
     while (t < t_frame) {
         domain.device();
         domain.particleSet().push();
+        domain.grid().push(); // velocities written through the MacGrid setters since the last step
         float timestep = compute_cfl(domain);
         if (timestep + t >= t_frame) { timestep = t_frame - t; }
         if (verbose) printf("Taking substep of size %f (to %0.3f%% of the frame)\n", timestep, 100 * (t + timestep) / t_frame);

@@ -58,6 +58,10 @@ void ParticleSet::advectAndEnsureOutsideObstacles(float dt) {
     _host_stale = true;
 }
 
+void ParticleSet::advectAndEnsureOutsideObstacles(Vec3dGrid::Ptr, Vec3fGrid::Ptr, LevelSet &, float dt) {
+    advectAndEnsureOutsideObstacles(dt);
+}
+
 void ParticleSet::getPos(size_t n, Vec3R &xyz) {
     pull();
     xyz = _i2w_transform->indexToWorld(_particles[n].pos());

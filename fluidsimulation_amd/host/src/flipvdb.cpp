@@ -1,6 +1,8 @@
 // flipvdb.cpp -- samplers and analytic level-set builders of the host grid vocabulary.
 #include "flipvdb.h"
 
+#include <cstdio>
+
 namespace flipvdb {
 
 namespace {
@@ -81,6 +83,37 @@ FloatGrid::Ptr createLevelSetCube(float scale, const Vec3d &center, float voxel_
     const Vec3d h(0.5 * scale);
     const Vec3d lo = xform.worldToIndex(center - h), hi = xform.worldToIndex(center + h);
     return bandGrid(lo, hi, half_width, voxel_size, [&](const Vec3d &p) { return boxDistance(p, lo, hi); });
+}
+
+FloatGrid::Ptr csgUnionCopy(const FloatGrid &a, const FloatGrid &b) {
+    const CoordBBox &ba = a.evalActiveVoxelBoundingBox(), &bb = b.evalActiveVoxelBoundingBox();
+    CoordBBox box(Coord(std::min(ba.mn[0], bb.mn[0]), std::min(ba.mn[1], bb.mn[1]), std::min(ba.mn[2], bb.mn[2])),
+                  Coord(std::max(ba.mx[0], bb.mx[0]), std::max(ba.mx[1], bb.mx[1]), std::max(ba.mx[2], bb.mx[2])));
+    auto out = FloatGrid::create(box, std::min(a.background(), b.background()));
+    out->setTransform(a.transform());
+    float *data = out->raw();
+#pragma omp parallel for schedule(static)
+    for (int k = box.mn[2]; k <= box.mx[2]; ++k)
+        for (int j = box.mn[1]; j <= box.mx[1]; ++j)
+            for (int i = box.mn[0]; i <= box.mx[0]; ++i) {
+                const Coord c(i, j, k);
+                data[out->index(i, j, k)] = std::min(a.getValue(c), b.getValue(c));
+            }
+    return out;
+}
+
+void io::File::write(const GridPtrVec &grids) {
+    FILE *f = std::fopen(_name.c_str(), "wb");
+    if (!f) return; // like the reference, which ignores I/O trouble
+    std::fprintf(f, "FLIPDENSE 1 grids %zu\n", grids.size());
+    for (const GridBase::Ptr &g : grids) {
+        const CoordBBox b = g->gridBox();
+        std::fprintf(f, "grid %s bytes %lld box %d %d %d %d %d %d\n", g->valueTypeName(), (long long)g->valueBytes(), b.mn[0], b.mn[1],
+                     b.mn[2], b.mx[0], b.mx[1], b.mx[2]);
+        std::fwrite(g->rawBytes(), (size_t)g->valueBytes(), (size_t)b.volume(), f);
+        std::fputc('\n', f);
+    }
+    std::fclose(f);
 }
 
 } // namespace flipvdb
