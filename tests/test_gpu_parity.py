@@ -724,3 +724,70 @@ def test_fluid_levelset_from_particles_matches_the_oracle_restatement():
             got = ctx.download("phi_fluid")
         assert np.array_equal(got, want)
         assert (got < 0).sum() > 500 and (got == got.max()).sum() > 500
+
+
+# ---- the benchmark configurations at full size: properties that do not need the oracle's solver ----
+
+def _substep_properties(ctx, sc, n_steps, rigid_body=False):
+    from fluidsimulation_amd import FlipSubstep, PRECOND_MULTIGRID
+    radius = 1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0
+    step = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, max_iter=5000, concurrent_solves=not rigid_body, constrain=True, advect=True,
+                       levelset_radius=radius, rigid_body=rigid_body)
+    for _ in range(n_steps):
+        info = step.step(0.004)
+        for k in ("divergence", "density"):
+            assert info[k]["converged"] == 1 and info[k]["rel_residual_2"] < RES_TOL, (k, info[k])
+    pos, vel = ctx.download_particles()
+    assert np.isfinite(pos).all() and np.isfinite(vel).all()
+    lo, hi = np.asarray(sc.box_lo), np.asarray(sc.box_hi)
+    assert np.all(pos > lo - 0.5) and np.all(pos < hi + 0.5)          # nothing left the container
+    assert ctx.bin_particles() == 0
+    cell_id, cell_start, perm = ctx.download_binning()
+    assert np.all(np.diff(cell_id[perm]) >= 0) and cell_start[-1] == pos.shape[0]
+    return info
+
+
+def test_config_cube_drop_128_p2g_against_the_oracle_and_substeps():
+    """BASELINE config 2 (cube drop at 128^3, 8 particles per cell, 2.1 M particles): binning and the P2G + density gather
+    bit for bit against the oracle at full size, then whole substeps with the size-independent checks."""
+    sc = scenes.cube_drop(128, ppc=8, seed=12345, exact_levelset=False)
+    rng = np.random.default_rng(3)
+    sc.vel = rng.normal(0.0, 0.2, sc.pos.shape)
+    o = Oracle(sc.desc(), threads=16)
+    cell_id, cell_start, perm, _ = o.bin_particles(sc.pos)
+    band2 = o.particle_mask(cell_start, 2)
+    want = o.p2g(sc.pos, sc.vel, cell_start, perm, band2)
+    want_density, _ = o.density(sc.pos, sc.mass, cell_start, perm, band2, sc.phi_fluid)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        assert ctx.bin_particles() == 0
+        got_id, got_start, got_perm = ctx.download_binning()
+        assert np.array_equal(got_id, cell_id) and np.array_equal(got_start, cell_start) and np.array_equal(got_perm, perm)
+        ctx.p2g()
+        for name, w in zip(("vel_u", "vel_v", "vel_w"), want):
+            assert np.array_equal(ctx.download(name), w), name
+        assert np.array_equal(ctx.download("density"), want_density)
+        _substep_properties(ctx, sc, 2)
+
+
+def test_config_floating_ball_128_substeps():
+    """BASELINE config 3 (config 2 plus the half-density sphere, strongly coupled): the coupled solve converges to the
+    reference tolerance at full size and the body's velocity stays finite and moves under gravity and pressure."""
+    sc = scenes.add_sphere(scenes.cube_drop(128, ppc=8, seed=12345, exact_levelset=False), density=500.0)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        info = _substep_properties(ctx, sc, 2, rigid_body=True)
+        v = ctx.solid_object_velocity()
+        assert np.isfinite(v).all()
+        assert info["divergence"]["rows"] > 200000
+
+
+def test_config_dam_break_256_substeps():
+    """BASELINE config 4 on one GPU (side-drop dam break at 256^3, 12.4 M particles, density projection on): sortedness,
+    residuals at the reference tolerance, containment, over whole substeps at full size."""
+    sc = scenes.dam_break_slab(256, ppc=8, seed=12345)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.reserve_particles(sc.pos.shape[0] + 4096)
+        ctx.upload_scene(sc)
+        info = _substep_properties(ctx, sc, 2)
+        assert info["divergence"]["cg_rows"] > 1400000
