@@ -63,7 +63,7 @@ EXPORTS = [
     "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_velocity_max_static", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_redistribute_overdense", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
     "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_project_velocity",
-    "flip_project_displacement", "flip_set_slab", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
+    "flip_project_displacement", "flip_set_slab", "flip_solid_coupling_partial", "flip_solid_velocity_apply", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
     "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish", "flip_set_slab_overlap",
     "flip_pcg_dist_precondition", "flip_pcg_dist_combine", "flip_particles_reserve", "flip_particles_pack",
     "flip_particles_exchange_apply",
@@ -128,6 +128,8 @@ def load_library(path: str = LIB_PATH):
         "flip_project_velocity": (C.c_int, [vp, f32]),
         "flip_project_displacement": (C.c_int, [vp, f32]),
         "flip_set_slab": (C.c_int, [vp, i32, i32]),
+        "flip_solid_coupling_partial": (C.c_int, [vp, P(f64)]),
+        "flip_solid_velocity_apply": (C.c_int, [vp, f32, P(f64)]),
         "flip_pcg_dist_buffer": (C.c_int, [vp, C.c_int, P(vp), P(i64)]),
         "flip_pcg_dist_begin": (C.c_int, [vp, f64, i32, C.c_int]),
         "flip_pcg_dist_direction": (C.c_int, [vp]),
@@ -384,6 +386,15 @@ class FlipContext:
     # ---- z-slab decomposition of the solve ----
     def set_slab(self, k0: int, k1: int):
         self._check(self.lib.flip_set_slab(self.h, k0, k1))
+
+    def solid_coupling_partial(self):
+        out = (C.c_double * 6)()
+        self._check(self.lib.flip_solid_coupling_partial(self.h, out))
+        return np.array(out[:], dtype=np.float64)
+
+    def solid_velocity_apply(self, dt: float, jp_total):
+        arr = (C.c_double * 6)(*[float(v) for v in jp_total])
+        self._check(self.lib.flip_solid_velocity_apply(self.h, dt, arr))
 
     def set_slab_overlap(self, planes: int):
         self._check(self.lib.flip_set_slab_overlap(self.h, planes))

@@ -600,7 +600,8 @@ extern "C" int flip_project_velocity(flip_ctx *ctx, float dt) {
         ctx->valid[0][0], ctx->valid[0][1], ctx->valid[0][2], ctx->active);
     FLIP_LAUNCH_CHECK();
     for (int a = 0; a < 3; ++a) std::swap(ctx->vel[0][a], ctx->vel[1][a]);
-    if (ctx->has_obj && ctx->sys_coupled) { // V += dt * Minv * (J p)   (src/FluidSimulator.cpp:1095-1100)
+    // on a slab context the sum J p spans every rank's rows: the caller completes it (flip_solid_coupling_partial)
+    if (ctx->has_obj && ctx->sys_coupled && !ctx->slab_on) { // V += dt * Minv * (J p)   (src/FluidSimulator.cpp:1095-1100)
         double jp[6];
         if (int rc = flip_pcg_coupling_jp(ctx, jp)) return rc;
         for (int a = 0; a < 6; ++a) ctx->obj_vel[a] = ctx->obj_vel[a] + (double)dt * (ctx->obj_minv[a] * jp[a]);

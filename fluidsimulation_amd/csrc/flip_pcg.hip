@@ -227,8 +227,8 @@ extern "C" int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1) {
         ctx->mg_cz = base + ctx->pad;
     }
     if (!ctx->dist_sums) {
-        FLIP_CHECK(hipMalloc((void **)&ctx->dist_sums, 8 * sizeof(double)));
-        FLIP_CHECK(hipMemset(ctx->dist_sums, 0, 8 * sizeof(double)));
+        FLIP_CHECK(hipMalloc((void **)&ctx->dist_sums, 16 * sizeof(double)));
+        FLIP_CHECK(hipMemset(ctx->dist_sums, 0, 16 * sizeof(double)));
     }
     ctx->slab_overlap = 0;
     ctx->sys_kind = -1; // a system assembled under another ownership is stale
@@ -1107,8 +1107,8 @@ extern "C" int flip_select_system(flip_ctx *ctx, int kind) {
 //     slab_k1-1, receive into planes slab_k0-1 and slab_k1) after begin() and after every update().
 // Every rank then sees identical scalars, takes identical branches and stops at the same iteration.  The
 // preconditioner (Jacobi, or the V-cycle over the rank's own rows) never reads across a slab face, so it is
-// block diagonal over the ranks: symmetric positive definite, no communication.  The rigid-body term is not
-// supported here.
+// block diagonal over the ranks: symmetric positive definite, no communication.  With a rigid body attached the six
+// sums J p of the rank-6 term travel in the same buffer as p.Ap.
 //
 // The global sums travel through the kernels' own reduction scheme: k_dist_gather folds this rank's
 // per-workgroup partials of the named slots into the buffer (other entries zero, so one all-reduce serves any
@@ -1118,7 +1118,7 @@ extern "C" int flip_select_system(flip_ctx *ctx, int kind) {
 __global__ void __launch_bounds__(FLIP_BLOCK) k_dist_gather(const double *__restrict__ partial, int nblk, int first, int count,
                                                            double *__restrict__ sums) {
     __shared__ double scratch[4];
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < 16; ++s) {
         double v = 0.0;
         if (s >= first && s < first + count) v = d_reduce_partials(partial + (size_t)s * FLIP_MAX_PCG_BLOCKS, nblk, scratch);
         if (threadIdx.x == 0) sums[s] = v;
@@ -1206,7 +1206,7 @@ extern "C" int flip_pcg_dist_buffer(flip_ctx *ctx, int which, void **ptr, int64_
     FLIP_REQUIRE(ctx && ptr && count, "flip_pcg_dist_buffer: null argument");
     FLIP_REQUIRE(ctx->dist_sums, "flip_pcg_dist_buffer: call flip_set_slab first");
     switch (which) {
-    case 0: *ptr = ctx->dist_sums; *count = 8; break;
+    case 0: *ptr = ctx->dist_sums; *count = 16; break;
     case 1: *ptr = ctx->z; *count = ctx->B; break;
     case 2: *ptr = ctx->x; *count = ctx->B; break;
     case 3: *ptr = ctx->r; *count = ctx->B; break;
@@ -1227,7 +1227,6 @@ extern "C" int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, 
     FLIP_REQUIRE(ctx->dist_sums, "flip_pcg_dist_begin: call flip_set_slab first");
     FLIP_REQUIRE(precond == FLIP_PRECOND_JACOBI || precond == FLIP_PRECOND_MULTIGRID, "flip_pcg_dist_begin: unknown preconditioner");
     FLIP_REQUIRE(ctx->sys_eliminated, "flip_pcg_dist_begin: needs eliminate_dependent_rows = 1 (symmetric system)");
-    FLIP_REQUIRE(!ctx->sys_coupled, "flip_pcg_dist_begin: the rigid-body coupling is not supported by the slab solver");
     FLIP_REQUIRE(tol > 0.0 && max_iter > 0, "flip_pcg_dist_begin: tol and max_iter must be positive");
     FLIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -1289,7 +1288,8 @@ extern "C" int flip_pcg_dist_direction(flip_ctx *ctx) {
     if (lo_ghost >= 0 || hi_ghost >= 0)
         k_dist_ghost_direction<<<flip_grid_blocks(plane), FLIP_BLOCK, 0, st>>>(ctx->scal, plane, lo_ghost, hi_ghost, ctx->z,
                                                                               ctx->pv[0], ctx->pv[1]);
-    k_dist_gather<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 2, 1, ctx->dist_sums);
+    // p.Ap and, with a rigid body, the six sums J p (the rank-6 term couples rows of every slab)
+    k_dist_gather<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 2, ctx->sys_coupled ? 7 : 1, ctx->dist_sums);
     FLIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1301,7 +1301,7 @@ extern "C" int flip_pcg_dist_update(flip_ctx *ctx) {
     PcgArgs A;
     fill_pcg_args(ctx, A);
     const int nblk = ctx->pcg_blocks;
-    k_dist_scatter<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 2, 1, ctx->dist_sums);
+    k_dist_scatter<<<1, FLIP_BLOCK, 0, st>>>(ctx->partial, nblk, 2, ctx->sys_coupled ? 7 : 1, ctx->dist_sums);
     k_pcg_update<<<nblk, FLIP_BLOCK, 0, st>>>(A);
     FLIP_LAUNCH_CHECK();
     if (ctx->slab_overlap > 0) return 0;
@@ -1420,7 +1420,8 @@ extern "C" int flip_pcg_dist_finish(flip_ctx *ctx, flip_pcg_info *info) {
 // ---------------------------------------------------------------------------------------------
 // Parity hooks
 
-__global__ void k_apply_plain(PcgArgs A, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ jp_out) {
+__global__ void k_apply_plain(PcgArgs A, long long own_lo, long long own_hi, const double *__restrict__ x, double *__restrict__ y,
+                              double *__restrict__ jp_out) {
     __shared__ double scratch[4];
     double jp[6] = { 0, 0, 0, 0, 0, 0 };
     for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < A.B; c += (long long)gridDim.x * blockDim.x) {
@@ -1428,7 +1429,7 @@ __global__ void k_apply_plain(PcgArgs A, const double *__restrict__ x, double *_
         double s = 0.0;
         if (fl & FLIP_FLAG_ROW) {
             s = d_apply_row(A, c, fl, x[c], [&](long long n) { return x[n]; });
-            if (A.coupled)
+            if (A.coupled && c >= own_lo && c < own_hi) // the rows of a slab's ghost planes belong to the neighbours' sums
 #pragma unroll
                 for (int a = 0; a < 6; ++a) jp[a] += A.J[a][c] * x[c];
         }
@@ -1452,7 +1453,9 @@ static int coupling_jv(flip_ctx *ctx, const double *dev_v, double *dev_y, double
     PcgArgs A;
     fill_pcg_args(ctx, A);
     const int nblk = 256;
-    k_apply_plain<<<nblk, FLIP_BLOCK, 0, ctx->stream>>>(A, dev_v, dev_y, ctx->d_vmax);
+    const long long plane = (long long)ctx->g.nx * ctx->g.ny;
+    const long long own_lo = ctx->slab_on ? ctx->slab_k0 * plane : 0, own_hi = ctx->slab_on ? ctx->slab_k1 * plane : ctx->B;
+    k_apply_plain<<<nblk, FLIP_BLOCK, 0, ctx->stream>>>(A, own_lo, own_hi, dev_v, dev_y, ctx->d_vmax);
     FLIP_LAUNCH_CHECK();
     for (int a = 0; a < 6; ++a) jv[a] = 0.0;
     if (A.coupled) {
@@ -1468,6 +1471,23 @@ static int coupling_jv(flip_ctx *ctx, const double *dev_v, double *dev_y, double
 int flip_pcg_coupling_jp(flip_ctx *ctx, double jp[6]) {
     FLIP_REQUIRE(ctx->sys_coupled, "no coupled system assembled");
     return coupling_jv(ctx, ctx->x, ctx->ap, jp);
+}
+
+// The rigid body under a slab decomposition: every rank holds the same body; its velocity update V += dt Minv (J p)
+// (src/FluidSimulator.cpp:1095-1100) needs J p over the rows of ALL slabs.  flip_solid_coupling_partial returns this
+// context's share (rows of its owned planes, after the solve), the caller sums the six numbers over the ranks and hands
+// the total to flip_solid_velocity_apply on every rank.  On a slab context flip_project_velocity leaves the body alone.
+extern "C" int flip_solid_coupling_partial(flip_ctx *ctx, double jp[6]) {
+    FLIP_REQUIRE(ctx && jp, "flip_solid_coupling_partial: null argument");
+    FLIP_REQUIRE(ctx->has_obj && ctx->sys_coupled, "flip_solid_coupling_partial: no coupled divergence system is active");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    return flip_pcg_coupling_jp(ctx, jp);
+}
+extern "C" int flip_solid_velocity_apply(flip_ctx *ctx, float dt, const double jp_total[6]) {
+    FLIP_REQUIRE(ctx && jp_total, "flip_solid_velocity_apply: null argument");
+    FLIP_REQUIRE(ctx->has_obj, "flip_solid_velocity_apply: no rigid body attached");
+    for (int a = 0; a < 6; ++a) ctx->obj_vel[a] = ctx->obj_vel[a] + (double)dt * (ctx->obj_minv[a] * jp_total[a]);
+    return 0;
 }
 
 extern "C" int flip_apply_operator(flip_ctx *ctx, const double *x_host, double *y_host) {

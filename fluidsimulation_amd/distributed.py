@@ -337,8 +337,9 @@ class DistributedSubstep:
     def __init__(self, ctx, layout: SlabLayout, comm: Comm, device: int = 0, flip_pic_ratio: float = 0.95,
                  tol: float = 1e-15, max_iter: int = 20000, precond: int = PRECOND_MULTIGRID,
                  density_projection: bool = True, overlap: int = 0, constrain: bool = False, advect: bool = False,
-                 levelset_radius: float | None = None):
+                 levelset_radius: float | None = None, rigid_body: bool = False):
         self.ctx, self.layout, self.comm = ctx, layout, comm
+        self.rigid_body = rigid_body   # every rank holds the same body (flip_solid_object_set) and the same velocity of it
         self.solver = ContextSlabSolver(ctx, layout, comm.rank, device, overlap=overlap)
         self.ratio, self.tol, self.max_iter, self.precond = flip_pic_ratio, tol, max_iter, precond
         self.density_projection = density_projection
@@ -361,6 +362,8 @@ class DistributedSubstep:
         c.extrapolate(2)
         if self.constrain:
             c.constrain_velocity(False)                             # :357
+            if self.rigid_body:
+                c.constrain_velocity(True)                          # :358-361
         c.update_prev()
         c.add_forces(dt)
         c.index_cells()
@@ -368,12 +371,22 @@ class DistributedSubstep:
         c.density(want_count=False)
         out = {"divergence": self.solve(SOLVE_DIVERGENCE, dt), "density": None}
         c.project_velocity(dt)
+        if self.rigid_body:
+            # V += dt Minv (J p), J p summed over every slab's rows (src/FluidSimulator.cpp:1095-1100)
+            import torch
+            jp = torch.from_numpy(c.solid_coupling_partial())
+            if self.comm.backend == "nccl":
+                jp = jp.cuda()
+            self.comm.all_reduce_sum(jp)
+            c.solid_velocity_apply(dt, jp.cpu().numpy())
         if self.density_projection:
             out["density"] = self.solve(SOLVE_DENSITY, dt)
             c.project_displacement(dt)
         c.extrapolate(2)
         if self.constrain:
             c.constrain_velocity(False)                             # :404
+            if self.rigid_body:
+                c.constrain_velocity(True)                          # :405-408
         c.update_diff()
         c.g2p(self.ratio)
         if self.advect:

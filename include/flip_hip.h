@@ -274,7 +274,7 @@ int flip_solver_kernel_times(flip_ctx *ctx, double us[6]);
  * rows this context owns (the default is the whole box).  It applies to the next flip_build_system.
  *
  * The solve is split into phases because two things cross ranks and the library does no communication of
- * its own: the caller all-reduces (sum) buffer 0 (8 doubles) after begin(), after every direction() and
+ * its own: the caller all-reduces (sum) buffer 0 (16 doubles) after begin(), after every direction() and
  * after every update(); and after begin() and every update() it sends planes k0 and k1-1 of buffer 1 (the
  * preconditioned residual, B doubles, plane k at offset k*nx*ny) to the lower / upper neighbour and receives
  * their planes into k0-1 and k1.  Iterate direction(), update() until flip_pcg_dist_status reports done != 0
@@ -282,6 +282,13 @@ int flip_solver_kernel_times(flip_ctx *ctx, double us[6]);
  * solution), and call finish(), which also fills FLIP_F_PRESSURE on the dependent rows.  The preconditioner
  * is applied per slab (block Jacobi over ranks with a V-cycle or point Jacobi inside each block). */
 int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1);
+/* The strongly coupled rigid body under slabs (src/FluidSimulator.cpp:810-816, 1095-1100): every rank attaches the same
+ * body; the six sums J p of the coupling term travel in buffer 0 with p.Ap, so the solve needs no further call.  After
+ * the solve and flip_project_velocity (which leaves the body alone on a slab context), flip_solid_coupling_partial
+ * returns this context's share of J p (rows of its owned planes); the caller sums it over the ranks and passes the total
+ * to flip_solid_velocity_apply on every rank: V += dt Minv (J p). */
+int flip_solid_coupling_partial(flip_ctx *ctx, double jp[6]);
+int flip_solid_velocity_apply(flip_ctx *ctx, float dt, const double jp_total[6]);
 int flip_pcg_dist_buffer(flip_ctx *ctx, int which, void **device_ptr, int64_t *count);
 int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, int precond);
 int flip_pcg_dist_direction(flip_ctx *ctx);
