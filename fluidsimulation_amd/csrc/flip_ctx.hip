@@ -133,7 +133,7 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
         if (c->pair_event[q]) (void)hipEventDestroy(c->pair_event[q]);
     for (hipEvent_t e : c->kprof)
         if (e) (void)hipEventDestroy(e);
-    dfree(c->cell_start); dfree(c->cell_fill); dfree(c->sub_start); dfree(c->scan_tmp);
+    dfree(c->cell_start); dfree(c->cell_fill); dfree(c->sub_start); dfree(c->scan_tmp); dfree(c->ls_list);
     dfree(c->phi_fluid); dfree(c->phi_solid); dfree(c->phi_obj);
     for (int b = 0; b < 4; ++b)
         for (int a = 0; a < 3; ++a) dfree(c->vel[b][a]);

@@ -122,6 +122,7 @@ struct flip_ctx {
                                     // sorted by half cell (see k_subrow_pack)
     flip_ppos *pcell = nullptr;     // [cap] positions + mass in the primary (cell) order, for the level-set search
     int32_t *sub_start = nullptr;   // [8 B + 1] run boundaries of the half-cell order: per grid row 4 sub-rows of 2 nx
+    int32_t *ls_list = nullptr;     // [B] cells left to the second pass of the level-set search (allocated on first use)
     int32_t *sub_slot = nullptr;    // [cap] place of primary slot s in the half-cell order
     bool prec_valid = false;
     bool binned = false;

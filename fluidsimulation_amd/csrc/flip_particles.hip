@@ -876,26 +876,20 @@ __device__ __forceinline__ void d_ls_range(const flip_ppos *__restrict__ pm, int
         }
     }
 }
+// The shell search of one column of R cells up to shell `last`; returns whether every cell of the column is finished
+// (its minimum cannot be beaten by a particle not yet visited).
 template <int R>
-__global__ void k_fluid_levelset(GridDims g, int nyb, float vs, double radius, double half_width, int reach,
-                                 const int32_t *__restrict__ cell_start, const flip_ppos *__restrict__ pm,
-                                 const uint8_t *__restrict__ near, const float *__restrict__ phi_solid, float *__restrict__ phi_fluid) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)g.nx * nyb * g.nz) return;
-    const int i = (int)(t % g.nx);
-    const long long tq = t / g.nx;
-    const int j0 = (int)(tq % nyb) * R, k = (int)(tq / nyb);
+__device__ __forceinline__ bool d_ls_search(const GridDims &g, int i, int j0, int k, int last, const int32_t *__restrict__ cell_start,
+                                            const flip_ppos *__restrict__ pm, double (&best2)[R]) {
     const int j1 = j0 + R - 1 < g.ny - 1 ? j0 + R - 1 : g.ny - 1; // last cell of the column inside the box
     const double cx = (double)(g.ox + i), cz = (double)(g.oz + k);
-    double cy[R], best2[R];
-    bool search = false;
+    double cy[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         cy[r] = (double)(g.oy + j0 + r);
         best2[r] = 1e300;
-        if (j0 + r < g.ny) search = search || near[d_lid(g, i, j0 + r, k)];
     }
-    for (int s = 0; s <= (search ? reach : -1); ++s) {
+    for (int s = 0; s <= last; ++s) {
         const int ya = j0 - s, yb = j1 + s;
         for (int dz = -s; dz <= s; ++dz) {
             const int kk = k + dz;
@@ -932,20 +926,73 @@ __global__ void k_fluid_levelset(GridDims g, int nyb, float vs, double radius, d
         bool done = true;
 #pragma unroll
         for (int r = 0; r < R; ++r) done = done && (j0 + r >= g.ny || best2[r] <= ((double)s + 0.5) * ((double)s + 0.5));
-        if (done) break;
+        if (done) return true;
     }
+    return false;
+}
+__device__ __forceinline__ void d_ls_store(const GridDims &g, long long c, double best2, float vs, double radius, double half_width,
+                                           const float *__restrict__ phi_solid, float *__restrict__ phi_fluid) {
+    double d = half_width;
+    // a particle beyond the reach of the band cannot bring the value below the band's edge
+    if (best2 < 1e299) d = sqrt(best2) - radius;
+    d = d < -half_width ? -half_width : (d > half_width ? half_width : d);
+    float f = (float)(d * (double)vs);
+    const float ps = phi_solid[c];
+    if (ps <= 0) f = f > -ps ? f : -ps;
+    phi_fluid[c] = f;
+}
+
+// First pass, every cell: shells 0 and 1 only.  Inside the liquid that settles the cell (a particle of the cell itself
+// or of a neighbour is nearer than any unvisited one); the cells that are not settled -- air and wall cells up to
+// `reach` cells away from the liquid, a thin layer, scattered a few to a wave -- are flagged for the second pass, which
+// runs over their compacted list with full waves instead of leaving 60 lanes of a wave idle behind 4 long searches.
+template <int R>
+__global__ void k_fluid_levelset_near(GridDims g, int nyb, float vs, double radius, double half_width, int reach,
+                                      const int32_t *__restrict__ cell_start, const flip_ppos *__restrict__ pm,
+                                      const uint8_t *__restrict__ near, const float *__restrict__ phi_solid,
+                                      float *__restrict__ phi_fluid, int32_t *__restrict__ far_flag) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) far_flag[g.B] = 0; // terminator of the scan
+    if (t >= (long long)g.nx * nyb * g.nz) return;
+    const int i = (int)(t % g.nx);
+    const long long tq = t / g.nx;
+    const int j0 = (int)(tq % nyb) * R, k = (int)(tq / nyb);
+    double best2[R];
+    bool search = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        best2[r] = 1e300;
+        if (j0 + r < g.ny) search = search || near[d_lid(g, i, j0 + r, k)];
+    }
+    bool done = true;
+    if (search) done = d_ls_search<R>(g, i, j0, k, reach < 1 ? reach : 1, cell_start, pm, best2) || reach <= 1;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (j0 + r >= g.ny) continue;
         const long long c = d_lid(g, i, j0 + r, k);
-        double d = half_width;
-        // a particle beyond the reach of the band cannot bring the value below the band's edge
-        if (best2[r] < 1e299) d = sqrt(best2[r]) - radius;
-        d = d < -half_width ? -half_width : (d > half_width ? half_width : d);
-        float f = (float)(d * (double)vs);
-        const float ps = phi_solid[c];
-        if (ps <= 0) f = f > -ps ? f : -ps;
-        phi_fluid[c] = f;
+        // a cell of an unfinished column may itself be finished: what shell 1 leaves is final if it is within 1.5
+        const bool settled = done || best2[r] <= 2.25;
+        far_flag[c] = settled ? 0 : 1;
+        if (settled) d_ls_store(g, c, best2[r], vs, radius, half_width, phi_solid, phi_fluid);
+    }
+}
+__global__ void k_fluid_levelset_list(long long B, const int32_t *__restrict__ scan, int32_t *__restrict__ list) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    if (scan[c + 1] > scan[c]) list[scan[c]] = (int32_t)c;
+}
+// Second pass: one thread per flagged cell, the whole search.
+__global__ void k_fluid_levelset_far(GridDims g, float vs, double radius, double half_width, int reach, const int32_t *__restrict__ cell_start,
+                                     const flip_ppos *__restrict__ pm, const int32_t *__restrict__ list, const int32_t *__restrict__ n_list,
+                                     const float *__restrict__ phi_solid, float *__restrict__ phi_fluid) {
+    const long long n = *n_list;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
+        const long long c = list[q];
+        int i, j, k;
+        d_ijk(g, c, i, j, k);
+        double best2[1];
+        d_ls_search<1>(g, i, j, k, reach, cell_start, pm, best2);
+        d_ls_store(g, c, best2[0], vs, radius, half_width, phi_solid, phi_fluid);
     }
 }
 
@@ -963,11 +1010,21 @@ extern "C" int flip_fluid_levelset_from_particles(flip_ctx *ctx, float radius_wo
     k_near_x<<<nb, FLIP_BLOCK, 0, ctx->stream>>>(g, reach, ctx->cell_start, ctx->tmp_u8);
     k_near_axis<<<nb, FLIP_BLOCK, 0, ctx->stream>>>(g, 1, reach, ctx->tmp_u8, ctx->seed);
     k_near_axis<<<nb, FLIP_BLOCK, 0, ctx->stream>>>(g, 2, reach, ctx->seed, ctx->tmp_u8);
-    constexpr int R = 3; // cells per thread: 1: 3.9 ms at 256^3, 2: 2.6, 3 and 4: 2.4
+    constexpr int R = 3; // cells per thread in the first pass
     const int nyb = (ctx->g.ny + R - 1) / R;
-    k_fluid_levelset<R><<<flip_grid_blocks((long long)ctx->g.nx * nyb * ctx->g.nz), FLIP_BLOCK, 0, ctx->stream>>>(
+    if (!ctx->ls_list) FLIP_CHECK(hipMalloc((void **)&ctx->ls_list, (size_t)ctx->B * 4));
+    k_fluid_levelset_near<R><<<flip_grid_blocks((long long)ctx->g.nx * nyb * ctx->g.nz), FLIP_BLOCK, 0, ctx->stream>>>(
         g, nyb, ctx->g.dx, radius, (double)half_width_voxels, reach, ctx->cell_start, ctx->pcell, ctx->tmp_u8, ctx->phi_solid,
-        ctx->phi_fluid);
+        ctx->phi_fluid, ctx->cg_scan);
+    FLIP_LAUNCH_CHECK();
+    if (reach > 1) {
+        // cg_scan is scratch of the system assembly, free here
+        if (int rc = flip_exclusive_scan(ctx, ctx->cg_scan, ctx->B + 1)) return rc;
+        k_fluid_levelset_list<<<nb, FLIP_BLOCK, 0, ctx->stream>>>(ctx->B, ctx->cg_scan, ctx->ls_list);
+        k_fluid_levelset_far<<<2048, FLIP_BLOCK, 0, ctx->stream>>>(g, ctx->g.dx, radius, (double)half_width_voxels, reach, ctx->cell_start,
+                                                                  ctx->pcell, ctx->ls_list, ctx->cg_scan + ctx->B, ctx->phi_solid,
+                                                                  ctx->phi_fluid);
+    }
     FLIP_LAUNCH_CHECK();
     ctx->density_valid = false;
     return 0;
