@@ -158,7 +158,7 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     FLIP_REQUIRE(desc->nx > 0 && desc->ny > 0 && desc->nz > 0, "flip_ctx_create: empty box");
     FLIP_REQUIRE((int64_t)desc->nx * desc->ny * desc->nz < (int64_t)2000000000, "flip_ctx_create: box too large for 32-bit cell ids");
     FLIP_REQUIRE(desc->dx > 0.f, "flip_ctx_create: dx must be positive");
-    FLIP_REQUIRE(8LL * desc->nx * 4 + 16 <= 60 * 1024, "flip_ctx_create: box too wide (nx) for the per-row half-cell index in LDS");
+    FLIP_REQUIRE(8LL * desc->nx * 4 + 16 <= 48 * 1024, "flip_ctx_create: box too wide (nx) for the per-row half-cell index in LDS");
     int ndev = 0;
     FLIP_CHECK(hipGetDeviceCount(&ndev));
     FLIP_REQUIRE(ndev > 0, "flip_ctx_create: no HIP device (this library has no CPU path)");

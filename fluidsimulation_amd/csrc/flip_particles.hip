@@ -115,9 +115,10 @@ struct ParticlePtrs {
     float *mass;
     int32_t *pid;
 };
-__global__ void k_reorder(long long n, const int32_t *__restrict__ slot_src, const int32_t *__restrict__ slot_key,
-                          ParticlePtrs src, ParticlePtrs dst, flip_ppos *__restrict__ pcell) {
-    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// the particles outside the box (the last bin): plain reorder; they take part in nothing until they return
+__global__ void k_reorder_outside(long long n, const int32_t *__restrict__ first, const int32_t *__restrict__ slot_src,
+                                  const int32_t *__restrict__ slot_key, ParticlePtrs src, ParticlePtrs dst, flip_ppos *__restrict__ pcell) {
+    const long long s = (long long)*first + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const int32_t o = slot_src[s];
     double v[6];
@@ -153,15 +154,21 @@ __device__ __forceinline__ int d_sub_index(const GridDims &g, double x, double y
     return (hz * 2 + hy) * (2 * g.nx) + 2 * ci + hx;
 }
 
-// One workgroup per grid row (j, k): counts the row's particles per half cell in LDS, scans, writes the row's 8 nx
-// entries of sub_start, and copies the records to their place in the half-cell order.  The rank of a particle inside
-// its half cell is the number of earlier slots of its cell that fall into the same half cell: the cell's slots are
-// sorted by upload index, so the half-cell order is too.  tmp_q / tmp_rank: two int32 scratch arrays over the slots.
-__global__ void __launch_bounds__(FLIP_BLOCK) k_subrow_pack(GridDims g, const int32_t *__restrict__ cell_start, ParticlePtrs src,
-                                                           int32_t *__restrict__ sub_start, int32_t *__restrict__ sub_slot,
-                                                           int32_t *__restrict__ tmp_q, int32_t *__restrict__ tmp_rank,
-                                                           flip_ppos *__restrict__ pm, flip_pvel *__restrict__ pv) {
-    extern __shared__ int32_t lds[]; // [8 nx] counts, then exclusive offsets; [4] wave totals
+// One workgroup per grid row (j, k) does the whole reordering of the row's particles: it gathers them from the previous
+// order (slot_src), counts them per half cell in LDS, scans, writes the row's 8 nx entries of sub_start, and stores every
+// particle three times -- SoA in the primary (cell, upload index) order, the position record of that order, and the
+// position and velocity records in the half-cell order.  The rank of a particle inside its half cell is the number of
+// earlier slots of its cell that fall into the same half cell (the cell's slots are sorted by upload index, so the
+// half-cell order is too); the half-cell numbers of the row are parked in LDS for that count (rows too crowded for
+// it use a scratch array in global memory).
+#define FLIP_ROW_QCAP 6144
+__global__ void __launch_bounds__(FLIP_BLOCK) k_reorder_pack(GridDims g, const int32_t *__restrict__ cell_start,
+                                                            const int32_t *__restrict__ slot_src, const int32_t *__restrict__ slot_key,
+                                                            ParticlePtrs src, ParticlePtrs dst, int32_t *__restrict__ sub_start,
+                                                            int32_t *__restrict__ sub_slot, int32_t *__restrict__ tmp_q,
+                                                            flip_ppos *__restrict__ pcell, flip_ppos *__restrict__ pm,
+                                                            flip_pvel *__restrict__ pv) {
+    extern __shared__ int32_t lds[]; // [8 nx] counts, then exclusive offsets; [4] wave totals; [FLIP_ROW_QCAP / 2] half-cell numbers (16 bit)
     const int nsub = 8 * g.nx;
     const long long row = blockIdx.x;
     const long long c0 = row * g.nx;
@@ -175,18 +182,18 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_subrow_pack(GridDims g, const in
         return;
     }
     for (int q = tid; q < nsub; q += FLIP_BLOCK) lds[q] = 0;
+    uint16_t *qbuf = reinterpret_cast<uint16_t *>(lds + nsub + 4);
+    const bool in_lds = r1 - r0 <= FLIP_ROW_QCAP; // uniform over the workgroup
     __syncthreads();
     const int j = (int)(row % g.ny), k = (int)(row / g.ny);
     for (int32_t s = r0 + tid; s < r1; s += FLIP_BLOCK) {
-        const double x = src.a[0][s], y = src.a[1][s], z = src.a[2][s];
+        const int32_t o = slot_src[s];
+        const double x = src.a[0][o], y = src.a[1][o], z = src.a[2][o];
         const int ci = (int)floor(x + 0.5) - g.ox;
         const int q = d_sub_index(g, x, y, z, ci, j, k);
-        int32_t rank = 0;
-        for (int32_t t = cell_start[c0 + ci]; t < s; ++t)
-            rank += d_sub_index(g, src.a[0][t], src.a[1][t], src.a[2][t], ci, j, k) == q ? 1 : 0;
         atomicAdd(&lds[q], 1); // integer: the totals do not depend on the order of arrival
-        tmp_q[s] = q;
-        tmp_rank[s] = rank;
+        if (in_lds) qbuf[s - r0] = (uint16_t)q;
+        else tmp_q[s] = q;
     }
     __syncthreads();
     // exclusive scan of lds[0 .. nsub): a run of consecutive entries per thread, wave scan of the run totals
@@ -215,14 +222,34 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_subrow_pack(GridDims g, const in
     for (int q = tid; q < nsub; q += FLIP_BLOCK) out[q] = lds[q];
     if (last && tid == 0) out[nsub] = r1;
     for (int32_t s = r0 + tid; s < r1; s += FLIP_BLOCK) {
-        const int32_t d = lds[tmp_q[s]] + tmp_rank[s];
+        const int32_t o = slot_src[s];
+        double v[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[a] = src.a[a][o];
+        const float m = src.mass[o];
+        const int ci = (int)floor(v[0] + 0.5) - g.ox;
+        const int32_t cs = cell_start[c0 + ci];
+        int q, rank = 0;
+        if (in_lds) {
+            q = qbuf[s - r0];
+            for (int32_t t = cs; t < s; ++t) rank += qbuf[t - r0] == q ? 1 : 0;
+        } else {
+            q = tmp_q[s];
+            for (int32_t t = cs; t < s; ++t) rank += tmp_q[t] == q ? 1 : 0;
+        }
+        const int32_t d = lds[q] + rank;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) dst.a[a][s] = v[a];
+        dst.mass[s] = m;
+        dst.pid[s] = slot_key[s];
         sub_slot[s] = d;
-        flip_ppos a;
-        a.x = src.a[0][s]; a.y = src.a[1][s]; a.z = src.a[2][s]; a.mass = src.mass[s]; a.pad0 = 0.f;
-        flip_pvel b;
-        b.vx = src.a[3][s]; b.vy = src.a[4][s]; b.vz = src.a[5][s]; b.pad1 = 0.0;
-        pm[d] = a;
-        pv[d] = b;
+        flip_ppos pa;
+        pa.x = v[0]; pa.y = v[1]; pa.z = v[2]; pa.mass = m; pa.pad0 = 0.f;
+        flip_pvel pb;
+        pb.vx = v[3]; pb.vy = v[4]; pb.vz = v[5]; pb.pad1 = 0.0;
+        pcell[s] = pa;
+        pm[d] = pa;
+        pv[d] = pb;
     }
 }
 // refresh of the packed records when the SoA arrays changed without a re-sort (velocities after G2P); n_inside_ptr:
@@ -252,7 +279,7 @@ static ParticlePtrs particle_ptrs(flip_ctx *ctx, int buffer) {
 
 static inline flip_ppos *packed_pos(flip_ctx *ctx) { return reinterpret_cast<flip_ppos *>(ctx->prec); }
 static inline flip_pvel *packed_vel(flip_ctx *ctx) { return reinterpret_cast<flip_pvel *>(reinterpret_cast<flip_ppos *>(ctx->prec) + ctx->cap); }
-static inline size_t subrow_lds_bytes(const flip_ctx *ctx) { return ((size_t)8 * ctx->g.nx + 4) * sizeof(int32_t); }
+static inline size_t subrow_lds_bytes(const flip_ctx *ctx) { return ((size_t)8 * ctx->g.nx + 4) * sizeof(int32_t) + FLIP_ROW_QCAP * sizeof(uint16_t); }
 
 // Occupancy bands: bit0 = within 1 cell of a particle cell, bit1 = within 2 (Chebyshev distance).
 // Box dilation is separable: one pass per axis.
@@ -321,19 +348,19 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
         FLIP_LAUNCH_CHECK();
         k_sort_cells<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(B, ctx->cell_start, ctx->slot_src, ctx->slot_key);
         FLIP_LAUNCH_CHECK();
-        ParticlePtrs ps, pd;
-        for (int q = 0; q < 6; ++q) { ps.a[q] = ctx->p[src][q]; pd.a[q] = ctx->p[dst][q]; }
-        ps.mass = ctx->mass[src]; pd.mass = ctx->mass[dst];
-        ps.pid = ctx->pid[src]; pd.pid = ctx->pid[dst];
-        k_reorder<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->slot_src, ctx->slot_key, ps, pd, ctx->pcell);
-        FLIP_LAUNCH_CHECK();
         ctx->cur = dst;
     }
-    // the half-cell ordered copy of the records and its index (also with no particles: the gathers read sub_start)
-    k_subrow_pack<<<(int)((long long)ctx->g.ny * ctx->g.nz), FLIP_BLOCK, subrow_lds_bytes(ctx), st>>>(
-        g, ctx->cell_start, particle_ptrs(ctx, ctx->cur), ctx->sub_start, ctx->sub_slot, ctx->slot_key, ctx->slot_src, packed_pos(ctx),
-        packed_vel(ctx));
+    // every grid row gathers its particles from the previous order and stores them in both orders (also with no particles:
+    // the gathers read sub_start); the particles outside the box, behind the last row, keep the plain reorder
+    k_reorder_pack<<<(int)((long long)ctx->g.ny * ctx->g.nz), FLIP_BLOCK, subrow_lds_bytes(ctx), st>>>(
+        g, ctx->cell_start, ctx->slot_src, ctx->slot_key, particle_ptrs(ctx, src), particle_ptrs(ctx, dst), ctx->sub_start, ctx->sub_slot,
+        ctx->cell_id, ctx->pcell, packed_pos(ctx), packed_vel(ctx));
     FLIP_LAUNCH_CHECK();
+    if (n > 0) {
+        k_reorder_outside<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->cell_start + B, ctx->slot_src, ctx->slot_key, particle_ptrs(ctx, src),
+                                                                     particle_ptrs(ctx, dst), ctx->pcell);
+        FLIP_LAUNCH_CHECK();
+    }
     ctx->prec_valid = true;
     k_band_x<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, ctx->cell_start, ctx->band);
     FLIP_LAUNCH_CHECK();
