@@ -23,9 +23,9 @@ with FlipContext(sc.desc(), device=0) as ctx:
     nx, ny, nz = ctx.dims
     p, n = ctx.dist_buffer(0)
     sums = device_tensor(p, n, 0)
-    sums.copy_(torch.arange(8, dtype=torch.float64, device="cuda"))
+    sums.copy_(torch.arange(n, dtype=torch.float64, device="cuda"))
     dist.all_reduce(sums)
-    assert sums.cpu().tolist() == list(range(8)), sums
+    assert sums.cpu().tolist() == list(range(n)), sums
     p, n = ctx.dist_buffer(1)
     z = device_tensor(p, n, 0).view(nz, nx * ny)
     z[3] = 7.0
