@@ -332,6 +332,94 @@ __global__ void __launch_bounds__(1024) k_mg_coarsest(MgDev<double> L, const int
     d_mg_coarsest(L, pad, lds);
 }
 
+// The small levels cost launch latency plus the latency of every *dependent* load, not bandwidth: the list-driven
+// kernels above read the stop flag, then the row count, then the row's cell, then the cell's data -- four round trips
+// for a few thousand rows.  The forms below take one thread per cell of the dense level instead (the cell index is the
+// thread index), issue every load at once, and test the stop flag and whether the cell is a row only before the store:
+// one round trip.  A cell that is not a row has zero diagonal, inverse, couplings and right-hand side (k_mg_coarsen,
+// k_mg_prune, the memsets of mg_coarsen_into), so the loads are harmless there.  Same expressions per row as the
+// list-driven forms, hence the same results bit for bit.
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_pre_dense(MgDev<double> L, const int32_t *done, double *__restrict__ out) {
+    const int stop = *done;
+    const long long c = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x;
+    if (c >= L.B) return;
+    const long long sy = L.sy, sz = L.sz;
+    const double *__restrict__ b = L.b, *__restrict__ inv = L.inv;
+    const double bc = b[c], ic = inv[c];
+    const double t0 = L.c1 * ic * bc;
+    double acc = L.cx[c] * (L.c1 * inv[c - 1] * b[c - 1]);
+    acc += L.cx[c + 1] * (L.c1 * inv[c + 1] * b[c + 1]);
+    acc += L.cy[c] * (L.c1 * inv[c - sy] * b[c - sy]);
+    acc += L.cy[c + sy] * (L.c1 * inv[c + sy] * b[c + sy]);
+    acc += L.cz[c] * (L.c1 * inv[c - sz] * b[c - sz]);
+    acc += L.cz[c + sz] * (L.c1 * inv[c + sz] * b[c + sz]);
+    const double At = L.diag[c] * t0 - L.scale * acc;
+    const double v = t0 + L.a2 * t0 + L.c2 * ic * (bc - At);
+    if (!stop && ic != 0.0) out[c] = v;
+}
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post_dense(MgDev<double> F, MgDev<double> C, const int32_t *done,
+                                                             const double *__restrict__ in, double *__restrict__ out) {
+    const int stop = *done;
+    const long long c = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x;
+    if (c >= F.B) return;
+    const double *__restrict__ xc = C.x;
+    const unsigned cu = (unsigned)c, tq = cu / (unsigned)F.nx;
+    const int i = (int)(cu - tq * (unsigned)F.nx);
+    const int k = (int)(tq / (unsigned)F.ny), j = (int)(tq - (unsigned)k * (unsigned)F.ny);
+    const long long pj = C.sy * (j >> 1), pk = C.sz * (k >> 1);
+    const long long pc = (i >> 1) + pj + pk;
+    const long long pxm = ((i - 1) >> 1) + pj + pk, pxp = ((i + 1) >> 1) + pj + pk;
+    const long long pym = (i >> 1) + C.sy * ((j - 1) >> 1) + pk, pyp = (i >> 1) + C.sy * ((j + 1) >> 1) + pk;
+    const long long pzm = (i >> 1) + pj + C.sz * ((k - 1) >> 1), pzp = (i >> 1) + pj + C.sz * ((k + 1) >> 1);
+    const long long sy = F.sy, sz = F.sz;
+    const double ic = F.inv[c];
+    const double v0 = in[c] + xc[pc];
+    double acc = F.cx[c] * (in[c - 1] + xc[pxm]);
+    acc += F.cx[c + 1] * (in[c + 1] + xc[pxp]);
+    acc += F.cy[c] * (in[c - sy] + xc[pym]);
+    acc += F.cy[c + sy] * (in[c + sy] + xc[pyp]);
+    acc += F.cz[c] * (in[c - sz] + xc[pzm]);
+    acc += F.cz[c + sz] * (in[c + sz] + xc[pzp]);
+    const double Av = F.diag[c] * v0 - F.scale * acc;
+    const double v = v0 + F.c1 * ic * (F.b[c] - Av);
+    if (!stop && ic != 0.0) out[c] = v;
+}
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth_dense(MgDev<double> L, MgDev<double> C, const int32_t *done,
+                                                               const double *__restrict__ in, double *out) {
+    const int stop = *done;
+    const long long c = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x;
+    if (c >= L.B) return;
+    const double ic = L.inv[c];
+    const double v = d_mg_second_step(L, C, c, in, out, L.b[c]);
+    if (!stop && ic != 0.0) out[c] = v;
+}
+// eight lanes per cell of the coarse level C, one per child
+__global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict_dense(MgDev<double> F, MgDev<double> C, const int32_t *done,
+                                                                 const double *__restrict__ v) {
+    const int stop = *done;
+    const long long t = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x;
+    const long long cc = t >> 3;
+    const int child = threadIdx.x & 7;
+    double s = 0.0;
+    if (cc < C.B) {
+        const unsigned cu = (unsigned)cc, tq = cu / (unsigned)C.nx;
+        const int I = (int)(cu - tq * (unsigned)C.nx);
+        const int K = (int)(tq / (unsigned)C.ny), J = (int)(tq - (unsigned)K * (unsigned)C.ny);
+        const int i = 2 * I + (child & 1), j = 2 * J + ((child >> 1) & 1), k = 2 * K + (child >> 2);
+        if (i < F.nx && j < F.ny && k < F.nz) {
+            const long long c = (long long)i + F.sy * j + F.sz * k;
+            const double ic = F.inv[c];
+            const double res = F.b[c] - d_mg_apply(F, c, v);
+            s = ic != 0.0 ? res : 0.0;
+        }
+    }
+    s += __shfl_xor(s, 1, FLIP_WAVE);
+    s += __shfl_xor(s, 2, FLIP_WAVE);
+    s += __shfl_xor(s, 4, FLIP_WAVE);
+    // a coarse cell none of whose children is a row is not a row itself and receives the zero it already holds
+    if (!stop && cc < C.B && child == 0) C.b[cc] = s;
+}
+
 // Galerkin coarsening with piecewise-constant transfer, scaled by 1/2 (see the header comment).
 template <class CT>
 __global__ void k_mg_coarsen(MgDev<CT> F, const double *__restrict__ fine_diag, int cnx, int cny, int cnz, long long csy, long long csz, double *__restrict__ cx,
@@ -537,6 +625,12 @@ static int mg_blocks(const flip_ctx *ctx, int64_t B) {
     return (int)(nb < 1 ? 1 : nb);
 }
 
+// levels of at most this many cells use the one-thread-per-cell kernels (FLIP_MG_DENSE_CELLS: tuning aid, 0 = never)
+static int64_t mg_dense_cells() {
+    static const int64_t v = [] { const char *e = getenv("FLIP_MG_DENSE_CELLS"); return e ? (int64_t)atoll(e) : (int64_t)131072; }();
+    return v;
+}
+
 // One V-cycle: z = M^-1 r on level 0, and the partials of r.z in slot 1 for the next direction kernel.
 int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed) {
     hipStream_t st = ctx->stream;
@@ -550,10 +644,14 @@ int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed) {
     if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[2], st));
     k_mg_restrict<float><<<mg_blocks(ctx, ctx->mg[0].B * 8), FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x);
     if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[3], st));
+    const int64_t dense_max = mg_dense_cells();
     for (size_t l = 0; l + 1 < nl; ++l) {
         MgDev<double> F = mg_level(ctx->mg[l]);
-        k_mg_pre<double><<<mg_blocks(ctx, ctx->mg[l].B), FLIP_BLOCK, 0, st>>>(F, done, F.x);
-        k_mg_restrict<double><<<mg_blocks(ctx, ctx->mg[l + 1].B * 8), FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x);
+        const int64_t B = ctx->mg[l].B, Bc = ctx->mg[l + 1].B;
+        if (B <= dense_max) k_mg_pre_dense<<<(unsigned)((B + FLIP_BLOCK - 1) / FLIP_BLOCK), FLIP_BLOCK, 0, st>>>(F, done, F.x);
+        else k_mg_pre<double><<<mg_blocks(ctx, B), FLIP_BLOCK, 0, st>>>(F, done, F.x);
+        if (Bc * 8 <= dense_max) k_mg_restrict_dense<<<(unsigned)((Bc * 8 + FLIP_BLOCK - 1) / FLIP_BLOCK), FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x);
+        else k_mg_restrict<double><<<mg_blocks(ctx, Bc * 8), FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x);
     }
     // ---- coarsest ----
     {
@@ -566,6 +664,12 @@ int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed) {
     for (size_t l = nl - 1; l-- > 0;) {
         MgDev<double> F = mg_level(ctx->mg[l]);
         const int nb = mg_blocks(ctx, ctx->mg[l].B);
+        if (ctx->mg[l].B <= dense_max) {
+            const unsigned nd = (unsigned)((ctx->mg[l].B + FLIP_BLOCK - 1) / FLIP_BLOCK);
+            k_mg_post_dense<<<nd, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x, F.t);
+            k_mg_smooth_dense<<<nd, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.t, F.x);
+            continue;
+        }
         k_mg_post<double><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x, F.t);
         k_mg_smooth<double, false><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.t, F.x, nullptr);
     }
