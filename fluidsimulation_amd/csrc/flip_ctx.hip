@@ -97,7 +97,8 @@ void flip_free_system(flip_ctx *c) {
     dfree(c->chunk_flag); dfree(c->chunk_list); dfree(c->d_counts); dfree(c->partial); dfree(c->scal);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     c->events.clear();
-    if (c->batch_exec) { (void)hipGraphExecDestroy(c->batch_exec); c->batch_exec = nullptr; }
+    for (hipGraphExec_t &e : c->batch_exec)
+        if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
 }
 
 void flip_swap_systems(flip_ctx *c) {
@@ -114,7 +115,7 @@ void flip_swap_systems(flip_ctx *c) {
     std::swap(c->partial, o.partial); std::swap(c->scal, o.scal);
     c->events.swap(o.events); c->mg.swap(o.mg);
     std::swap(c->mg_diag_f, o.mg_diag_f); std::swap(c->mg_inv_f, o.mg_inv_f);
-    std::swap(c->batch_exec, o.batch_exec); std::swap(c->batch_key, o.batch_key);
+    for (int q = 0; q < 2; ++q) { std::swap(c->batch_exec[q], o.batch_exec[q]); std::swap(c->batch_key[q], o.batch_key[q]); }
 }
 
 extern "C" void flip_ctx_destroy(flip_ctx *c) {

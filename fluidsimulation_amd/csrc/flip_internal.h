@@ -91,8 +91,8 @@ struct flip_system_set {
     std::vector<hipEvent_t> events;
     std::vector<flip_mg_level> mg;
     float *mg_diag_f = nullptr, *mg_inv_f = nullptr;
-    hipGraphExec_t batch_exec = nullptr;
-    uint64_t batch_key = 0;
+    hipGraphExec_t batch_exec[2] = { nullptr, nullptr };
+    uint64_t batch_key[2] = { 0, 0 };
     bool allocated = false;
 };
 
@@ -192,9 +192,11 @@ struct flip_ctx {
     std::vector<flip_mg_level> mg;  // coarse levels, finest first
     float *mg_diag_f = nullptr, *mg_inv_f = nullptr; // float copies of cg_diag / cg_inv for the V-cycle's level 0 (one allocation)
     // one batch of solver iterations as an instantiated graph (the kernels' arguments do not change from solve to
-    // solve; batch_key says which arguments it was captured with)
-    hipGraphExec_t batch_exec = nullptr;
-    uint64_t batch_key = 0;
+    // solve; batch_key says which arguments it was captured with); [0] the long batch, [1] the short one used near the
+    // expected end of a solve
+    hipGraphExec_t batch_exec[2] = { nullptr, nullptr };
+    uint64_t batch_key[2] = { 0, 0 };
+    int32_t last_iterations[2] = { 0, 0 };   // iterations the last solve of each kind took (0: none yet)
 
     // ---- second system and the two streams of flip_solve_pair ----
     flip_system_set other;

@@ -835,6 +835,22 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
 
 static int pcg_batch_direct(flip_ctx *ctx, PcgRun &run, int batch, bool allow_events);
 
+// Iterations per launch batch of a multigrid solve (the host reads the stop flag after each batch), and how the batches
+// are sized: long ones while the solve is sure to need them, short ones around the iteration count the last solve of
+// the same kind took (consecutive substeps need nearly the same number), so that few launches run after convergence
+// and the stop flag is read once or twice per solve instead of every 8 iterations.
+#define FLIP_MG_BATCH 8
+#define FLIP_MG_BATCH_SHORT 2
+static int mg_next_batch(int launched, int expected) {
+    if (expected <= 0) return FLIP_MG_BATCH;
+    // the direction kernel of iteration `expected` (counted from 0) is the one that sees the converged residual
+    const int target = expected + 1;
+    if (launched + FLIP_MG_BATCH <= target) return FLIP_MG_BATCH;
+    if (launched < target + 2 * FLIP_MG_BATCH_SHORT) return FLIP_MG_BATCH_SHORT;
+    return FLIP_MG_BATCH;
+}
+// whether the stop flag is worth reading after a batch: not while the solve cannot have converged yet
+static bool mg_check_after(int launched, int expected) { return expected <= 0 || launched >= expected + 1; }
 static bool pcg_graphs_enabled() {
     static const bool on = [] { const char *e = getenv("FLIP_GRAPHS"); return !(e && atoi(e) == 0); }();
     return on;
@@ -859,8 +875,9 @@ static int pcg_batch(flip_ctx *ctx, PcgRun &run, int batch, bool as_graph) {
     const int extra[5] = { batch, run.use_mg ? 1 : 0, run.sym ? 1 : 0, (int)ctx->mg.size(), run.fused ? 1 : 0 };
     mix(extra, sizeof extra);
     mix(&ctx->mg_diag_f, sizeof ctx->mg_diag_f);
-    if (!ctx->batch_exec || ctx->batch_key != key) {
-        if (ctx->batch_exec) { FLIP_CHECK(hipGraphExecDestroy(ctx->batch_exec)); ctx->batch_exec = nullptr; }
+    const int slot = batch == FLIP_MG_BATCH ? 0 : 1;
+    if (!ctx->batch_exec[slot] || ctx->batch_key[slot] != key) {
+        if (ctx->batch_exec[slot]) { FLIP_CHECK(hipGraphExecDestroy(ctx->batch_exec[slot])); ctx->batch_exec[slot] = nullptr; }
         hipGraph_t graph = nullptr;
         FLIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         PcgRun scratch = run;
@@ -868,12 +885,12 @@ static int pcg_batch(flip_ctx *ctx, PcgRun &run, int batch, bool as_graph) {
         const hipError_t e = hipStreamEndCapture(st, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         FLIP_CHECK(e);
-        const hipError_t ei = hipGraphInstantiate(&ctx->batch_exec, graph, nullptr, nullptr, 0);
+        const hipError_t ei = hipGraphInstantiate(&ctx->batch_exec[slot], graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         FLIP_CHECK(ei);
-        ctx->batch_key = key;
+        ctx->batch_key[slot] = key;
     }
-    FLIP_CHECK(hipGraphLaunch(ctx->batch_exec, st));
+    FLIP_CHECK(hipGraphLaunch(ctx->batch_exec[slot], st));
     run.launched += batch;
     return 0;
 }
@@ -935,6 +952,7 @@ static int pcg_enqueue_tail(flip_ctx *ctx, PcgTail &t) {
 }
 static int pcg_report(flip_ctx *ctx, const PcgRun &run, const PcgTail &t, flip_pcg_info *info) {
     ctx->n_active_chunks = t.counts[1];
+    if (run.use_mg && t.h.done == 1) ctx->last_iterations[ctx->sys_kind & 1] = t.h.it_a;
     if (!info) return 0;
     memset(info, 0, sizeof *info);
     info->converged = t.h.done == 1 ? 1 : 0;
@@ -974,12 +992,13 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
     FLIP_CHECK(hipEventRecord(ctx->pair_event[2], main_stream));
     FLIP_CHECK(hipStreamWaitEvent(st, ctx->pair_event[2], 0));
     ctx->stream = st;
-    const int batch = run.use_mg ? 8 : 32;
+    const int expected = ctx->last_iterations[ctx->sys_kind & 1];
     int32_t done = 0;
     int rc = 0;
     // one extra direction launch decides convergence after the last update
     while (!rc && !done && run.launched <= run.max_iter) {
-        rc = pcg_batch(ctx, run, batch, false);
+        rc = pcg_batch(ctx, run, run.use_mg ? mg_next_batch(run.launched, expected) : 32, false);
+        if (!rc && run.use_mg && !mg_check_after(run.launched, expected) && run.launched <= run.max_iter) continue;
         if (!rc && hipMemcpyAsync(&done, &ctx->scal->done, 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = flip_fail(ctx, "hipMemcpyAsync of the stop flag", __FILE__, __LINE__);
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = flip_fail(ctx, "hipStreamSynchronize in the solver loop", __FILE__, __LINE__);
     }
@@ -1047,10 +1066,18 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
         FLIP_CHECK(hipEventRecord(ctx->pair_event[2], ctx->pair_stream[0]));
         FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[1], ctx->pair_event[2], 0));
     }
+    const int expected[2] = { ctx->last_iterations[FLIP_SOLVE_DIVERGENCE], ctx->last_iterations[FLIP_SOLVE_DENSITY] };
     while (active[0] || active[1]) {
-        for (int q = 0; q < 2; ++q)
-            if (active[q])
-                if ((rc = with_system(q, [&] { return pcg_batch(ctx, run[q], run[q].use_mg ? 8 : 32, true); }))) return rc;
+        // batches of both solves, alternating, until one of them is due for a look at its stop flag
+        for (bool more = true; more;) {
+            more = true;
+            for (int q = 0; q < 2; ++q)
+                if (active[q]) {
+                    const int batch = run[q].use_mg ? mg_next_batch(run[q].launched, expected[q]) : 32;
+                    if ((rc = with_system(q, [&] { return pcg_batch(ctx, run[q], batch, true); }))) return rc;
+                    if (!run[q].use_mg || mg_check_after(run[q].launched, expected[q]) || run[q].launched > run[q].max_iter) more = false;
+                }
+        }
         for (int q = 0; q < 2; ++q)
             if (active[q]) {
                 const flip_pcg_scalars *sc = q == 0 ? ctx->scal : ctx->other.scal;
