@@ -116,6 +116,7 @@ void flip_swap_systems(flip_ctx *c) {
     c->events.swap(o.events); c->mg.swap(o.mg);
     std::swap(c->mg_diag_f, o.mg_diag_f); std::swap(c->mg_inv_f, o.mg_inv_f);
     for (int q = 0; q < 2; ++q) { std::swap(c->batch_exec[q], o.batch_exec[q]); std::swap(c->batch_key[q], o.batch_key[q]); }
+    std::swap(c->cg_scan, o.cg_scan); std::swap(c->scan_tmp, o.scan_tmp); std::swap(c->scan_tmp_len, o.scan_tmp_len);
 }
 
 extern "C" void flip_ctx_destroy(flip_ctx *c) {
@@ -145,7 +146,7 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
     for (int a = 0; a < 6; ++a) dfree(c->J[a]);
     dfree(c->density); dfree(c->active); dfree(c->active_back); dfree(c->label); dfree(c->band);
     dfree(c->seed); dfree(c->tmp_u8); dfree(c->row_index);
-    dfree(c->cg_scan);
+    dfree(c->cg_scan); dfree(c->other.cg_scan); dfree(c->other.scan_tmp);
     if (c->mg_cz) (void)hipFree(c->mg_cz - c->pad);
     dfree(c->dist_sums); dfree(c->mg_rows); dfree(c->dist_recv[0]); dfree(c->dist_recv[1]);
     if (c->dist_rw) (void)hipFree(c->dist_rw - c->pad);

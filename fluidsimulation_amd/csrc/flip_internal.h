@@ -93,6 +93,8 @@ struct flip_system_set {
     float *mg_diag_f = nullptr, *mg_inv_f = nullptr;
     hipGraphExec_t batch_exec[2] = { nullptr, nullptr };
     uint64_t batch_key[2] = { 0, 0 };
+    int32_t *cg_scan = nullptr, *scan_tmp = nullptr;   // scan scratch: the two systems are set up side by side
+    int64_t scan_tmp_len = 0;
     bool allocated = false;
 };
 

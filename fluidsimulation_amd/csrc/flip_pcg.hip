@@ -50,7 +50,7 @@ struct BuildArgs {
 __global__ void k_build_system(BuildArgs A) {
     const GridDims &g = A.g;
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int is_row = 0;
+    int is_row = 0, dep = 0, dep_coupled = 0;
     if (c < g.B) {
         int i, j, k;
         d_ijk(g, c, i, j, k);
@@ -132,9 +132,8 @@ __global__ void k_build_system(BuildArgs A) {
                 // A labelled cell that is not liquid enters no other row (an off-diagonal needs phi < 0 at the
                 // neighbour), so the matrix is block lower triangular: [liquid rows | 0 ; C | diag].
                 fl |= FLIP_FLAG_DEP;
-                atomicAdd(A.counters + 4, 1);
-                if (A.coupled && (Jr[0] != 0 || Jr[1] != 0 || Jr[2] != 0 || Jr[3] != 0 || Jr[4] != 0 || Jr[5] != 0))
-                    atomicAdd(A.counters + 5, 1);
+                dep = 1;
+                if (A.coupled && (Jr[0] != 0 || Jr[1] != 0 || Jr[2] != 0 || Jr[3] != 0 || Jr[4] != 0 || Jr[5] != 0)) dep_coupled = 1;
             }
         }
         // CG view: rows that take part in the CG iteration; the coupling of two such rows is symmetric
@@ -151,6 +150,15 @@ __global__ void k_build_system(BuildArgs A) {
         if (A.coupled)
 #pragma unroll
             for (int a = 0; a < 6; ++a) A.J[a][c] = Jr[a];
+    }
+    // one atomic per wave for the two counters (dependent rows cluster along the free surface: per-row atomics on one
+    // address serialise)
+    if (A.eliminate) {
+        const unsigned long long m = __ballot(dep), mc = __ballot(dep_coupled);
+        if ((threadIdx.x & (FLIP_WAVE - 1)) == 0) {
+            if (m) atomicAdd(A.counters + 4, (int)__popcll(m));
+            if (mc) atomicAdd(A.counters + 5, (int)__popcll(mc));
+        }
     }
     const int any = __syncthreads_or(is_row);
     if (threadIdx.x == 0) A.chunk_flag[blockIdx.x] = any ? 1 : 0;
@@ -1026,29 +1034,24 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
     if (int rc0 = pair_streams(ctx)) return rc0;
     if (!ctx->other.allocated) {
         flip_swap_systems(ctx);
-        const int rc = flip_alloc_system(ctx);
+        int rc = flip_alloc_system(ctx);
+        if (!rc && hipMalloc((void **)&ctx->cg_scan, (size_t)(ctx->B + 1) * 4) != hipSuccess)
+            rc = flip_fail(ctx, "hipMalloc of the second system's scan scratch", __FILE__, __LINE__);
         flip_swap_systems(ctx);
         if (rc) return rc;
         ctx->other.allocated = true;
     }
-    // make the density system the other set and the divergence system the active one
+    // The density system lives in the other set, the divergence system in the active one.  Assembly and solver set-up of
+    // each (coarse operators, row lists: several dozen small launches) already run on the solve's own stream, side by
+    // side with the other's; every scratch array they use belongs to the system set.
     PcgRun run[2];
     int rc = 0;
-    flip_swap_systems(ctx);
-    FLIP_CHECK(hipMemcpyAsync(ctx->d_counts, ctx->other.d_counts, 4, hipMemcpyDeviceToDevice, main_stream)); // rows of index_cells
-    rc = flip_build_system(ctx, FLIP_SOLVE_DENSITY, dt);
-    if (!rc) rc = pcg_prepare(ctx, tol, max_iter, precond, run[1], "flip_solve_pair");
-    flip_swap_systems(ctx);
-    if (rc) return rc;
-    if ((rc = flip_build_system(ctx, FLIP_SOLVE_DIVERGENCE, dt))) return rc;
-    if ((rc = pcg_prepare(ctx, tol, max_iter, precond, run[0], "flip_solve_pair"))) return rc;
-    // both solve streams start after everything enqueued so far
     FLIP_CHECK(hipEventRecord(ctx->pair_event[2], main_stream));
     FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[0], ctx->pair_event[2], 0));
     FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[1], ctx->pair_event[2], 0));
     int32_t done[2] = { 0, 0 };
     bool active[2] = { true, true };
-    // from here on ctx->stream is the stream of whichever system is active; restored before returning
+    // ctx->stream is the stream of whichever system is active; restored before returning
     auto with_system = [&](int q, auto &&fn) -> int {
         if (q == 1) flip_swap_systems(ctx);
         ctx->stream = ctx->pair_stream[q];
@@ -1057,10 +1060,25 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
         if (q == 1) flip_swap_systems(ctx);
         return r;
     };
+    rc = with_system(1, [&]() -> int {
+        // the row count of index_cells sits with the system that was active then
+        FLIP_CHECK(hipMemcpyAsync(ctx->d_counts, ctx->other.d_counts, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (int r = flip_build_system(ctx, FLIP_SOLVE_DENSITY, dt)) return r;
+        return pcg_prepare(ctx, tol, max_iter, precond, run[1], "flip_solve_pair");
+    });
+    if (rc) return rc;
+    rc = with_system(0, [&]() -> int {
+        if (int r = flip_build_system(ctx, FLIP_SOLVE_DIVERGENCE, dt)) return r;
+        return pcg_prepare(ctx, tol, max_iter, precond, run[0], "flip_solve_pair");
+    });
+    if (rc) return rc;
     if (ctx->profiling) {
         // the direction kernels bracketed by events run with the device to themselves: two iterations of the divergence
         // solve before the density solve's stream is released
-        // (the first iteration untimed: its launch follows a host-side pause, and the gap would be charged to the kernel)
+        // (the first iteration untimed: its launch follows a host-side pause, and the gap would be charged to the kernel);
+        // the set-up of the density system on the other stream must have drained first
+        FLIP_CHECK(hipEventRecord(ctx->pair_event[2], ctx->pair_stream[1]));
+        FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[0], ctx->pair_event[2], 0));
         if ((rc = with_system(0, [&] { return pcg_batch_direct(ctx, run[0], 1, false); }))) return rc;
         if ((rc = with_system(0, [&] { return pcg_batch_direct(ctx, run[0], 1, true); }))) return rc;
         FLIP_CHECK(hipEventRecord(ctx->pair_event[2], ctx->pair_stream[0]));
