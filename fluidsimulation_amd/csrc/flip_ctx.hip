@@ -24,11 +24,17 @@ int flip_fail_hip(flip_ctx *ctx, hipError_t e, const char *what, const char *fil
 
 extern "C" const char *flip_last_error(const flip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+hipError_t flip_zero_new(void *p, size_t bytes) {
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return e;
+}
+
 template <class T>
 static hipError_t dalloc(T **p, int64_t count) {
     hipError_t e = hipMalloc((void **)p, (size_t)(count > 0 ? count : 1) * sizeof(T));
     if (e != hipSuccess) { *p = nullptr; return e; }
-    e = hipMemset(*p, 0, (size_t)(count > 0 ? count : 1) * sizeof(T));
+    e = flip_zero_new(*p, (size_t)(count > 0 ? count : 1) * sizeof(T));
     if (e != hipSuccess) { (void)hipFree(*p); *p = nullptr; } // callers offset or free only pointers that are fully set up
     return e;
 }
@@ -464,6 +470,13 @@ static int scan_rec(flip_ctx *ctx, int32_t *data, int64_t n, int32_t *tmp, int64
     FLIP_LAUNCH_CHECK();
     if (int rc = scan_rec(ctx, tmp, nb, tmp + nb, tmp_len - nb)) return rc;
     k_scan_add<<<(int)nb, FLIP_BLOCK, 0, ctx->stream>>>(data, n, tmp);
+    FLIP_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void k_copy_i32(int32_t *__restrict__ dst, const int32_t *__restrict__ src) { dst[0] = src[0]; }
+int flip_copy_i32(flip_ctx *ctx, int32_t *dst, const int32_t *src, hipStream_t st) {
+    k_copy_i32<<<1, 1, 0, st>>>(dst, src);
     FLIP_LAUNCH_CHECK();
     return 0;
 }

@@ -210,7 +210,7 @@ extern "C" int flip_index_cells(flip_ctx *ctx, int32_t *n_rows) {
                                                           ctx->wgt[2], ctx->label, ctx->row_index);
     FLIP_LAUNCH_CHECK();
     if (int rc = flip_exclusive_scan(ctx, ctx->row_index, B + 1)) return rc;
-    FLIP_CHECK(hipMemcpyAsync(ctx->d_counts, ctx->row_index + B, 4, hipMemcpyDeviceToDevice, st));
+    if (int rc = flip_copy_i32(ctx, ctx->d_counts, ctx->row_index + B, st)) return rc;
     k_finish_index<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(B, ctx->label, ctx->row_index);
     FLIP_LAUNCH_CHECK();
     int32_t n = 0;

@@ -232,6 +232,14 @@ int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed = false);  // z = M^-1 r and
 void flip_mg_free(flip_ctx *ctx);
 void flip_mg_smoother(double *c1, double *a2, double *c2); // coefficients of the level smoother (see flip_mg.hip)
 
+// dst[0] = src[0] on the device, as a one-thread kernel on `st`: stays inside the stream's kernel order whatever the
+// runtime does with small device-to-device copies
+int flip_copy_i32(flip_ctx *ctx, int32_t *dst, const int32_t *src, hipStream_t st);
+// Zeroes freshly allocated device memory and waits for it.  hipMemset runs on the null stream and may return before
+// the fill has executed; the solver's own streams are non-blocking and not ordered against it, so a kernel on one of
+// them could otherwise write the new array before the fill does.  Allocation time only.
+hipError_t flip_zero_new(void *p, size_t bytes);
+
 int flip_fail(flip_ctx *ctx, const char *what, const char *file, int line);
 int flip_fail_hip(flip_ctx *ctx, hipError_t e, const char *what, const char *file, int line);
 

@@ -490,7 +490,7 @@ __global__ void k_mg_narrow(long long B, const double *__restrict__ diag, const 
 static hipError_t mg_alloc_padded(double **p, int64_t n, int64_t pad) {
     hipError_t e = hipMalloc((void **)p, (size_t)(n + 2 * pad) * sizeof(double));
     if (e != hipSuccess) return e;
-    e = hipMemset(*p, 0, (size_t)(n + 2 * pad) * sizeof(double));
+    e = flip_zero_new(*p, (size_t)(n + 2 * pad) * sizeof(double));
     *p += pad;
     return e;
 }
@@ -587,7 +587,7 @@ static int mg_coarsen_into(flip_ctx *ctx, const MgDev<CT> &F, const double *fine
     if (int rc = flip_exclusive_scan(ctx, S.scan, S.B + 1)) return rc;
     k_mg_compact<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.B, S.scan, S.rows);
     FLIP_LAUNCH_CHECK();
-    FLIP_CHECK(hipMemcpyAsync(S.n_rows, S.scan + S.B, 4, hipMemcpyDeviceToDevice, st));
+    if (int rc = flip_copy_i32(ctx, S.n_rows, S.scan + S.B, st)) return rc;
     // vectors of a previous solve may be non-zero on cells that are no longer rows
     FLIP_CHECK(hipMemsetAsync(S.x, 0, (size_t)S.B * 8, st));
     FLIP_CHECK(hipMemsetAsync(S.t, 0, (size_t)S.B * 8, st));
@@ -607,7 +607,7 @@ int flip_mg_setup(flip_ctx *ctx) {
     if (!ctx->mg_diag_f) {
         float *base = nullptr;
         FLIP_CHECK(hipMalloc((void **)&base, 2 * (size_t)(ctx->B + 2 * ctx->pad) * sizeof(float)));
-        FLIP_CHECK(hipMemset(base, 0, 2 * (size_t)(ctx->B + 2 * ctx->pad) * sizeof(float)));
+        FLIP_CHECK(flip_zero_new(base, 2 * (size_t)(ctx->B + 2 * ctx->pad) * sizeof(float)));
         ctx->mg_diag_f = base + ctx->pad;
         ctx->mg_inv_f = base + (ctx->B + 2 * ctx->pad) + ctx->pad;
     }

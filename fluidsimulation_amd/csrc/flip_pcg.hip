@@ -231,12 +231,12 @@ extern "C" int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1) {
         // padded like the other coupling arrays: the stencil kernels read one plane beyond either end
         float *base = nullptr;
         FLIP_CHECK(hipMalloc((void **)&base, (size_t)(ctx->B + 2 * ctx->pad) * sizeof(float)));
-        FLIP_CHECK(hipMemset(base, 0, (size_t)(ctx->B + 2 * ctx->pad) * sizeof(float)));
+        FLIP_CHECK(flip_zero_new(base, (size_t)(ctx->B + 2 * ctx->pad) * sizeof(float)));
         ctx->mg_cz = base + ctx->pad;
     }
     if (!ctx->dist_sums) {
         FLIP_CHECK(hipMalloc((void **)&ctx->dist_sums, 16 * sizeof(double)));
-        FLIP_CHECK(hipMemset(ctx->dist_sums, 0, 16 * sizeof(double)));
+        FLIP_CHECK(flip_zero_new(ctx->dist_sums, 16 * sizeof(double)));
     }
     ctx->slab_overlap = 0;
     ctx->sys_kind = -1; // a system assembled under another ownership is stale
@@ -263,7 +263,7 @@ extern "C" int flip_set_slab_overlap(flip_ctx *ctx, int32_t planes) {
         for (int s = 0; s < 2; ++s)
             if (!ctx->dist_recv[s]) {
                 FLIP_CHECK(hipMalloc((void **)&ctx->dist_recv[s], (size_t)(planes + 1) * plane * 8));
-                FLIP_CHECK(hipMemset(ctx->dist_recv[s], 0, (size_t)(planes + 1) * plane * 8));
+                FLIP_CHECK(flip_zero_new(ctx->dist_recv[s], (size_t)(planes + 1) * plane * 8));
             }
     }
     ctx->slab_overlap = ctx->slab_on ? planes : 0;
@@ -275,7 +275,7 @@ extern "C" int flip_set_slab_overlap(flip_ctx *ctx, int32_t planes) {
     if (ctx->slab_weighted && !ctx->dist_rw) {
         double *base = nullptr;
         FLIP_CHECK(hipMalloc((void **)&base, (size_t)(ctx->B + 2 * ctx->pad) * sizeof(double)));
-        FLIP_CHECK(hipMemset(base, 0, (size_t)(ctx->B + 2 * ctx->pad) * sizeof(double)));
+        FLIP_CHECK(flip_zero_new(base, (size_t)(ctx->B + 2 * ctx->pad) * sizeof(double)));
         ctx->dist_rw = base + ctx->pad;
     }
     ctx->sys_kind = -1;
@@ -344,7 +344,7 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     if (int rc = flip_exclusive_scan(ctx, ctx->chunk_flag, ctx->n_chunks + 1)) return rc;
     k_compact_chunks<<<flip_grid_blocks(ctx->n_chunks), FLIP_BLOCK, 0, st>>>(ctx->n_chunks, ctx->chunk_flag, nullptr, ctx->chunk_list);
     FLIP_LAUNCH_CHECK();
-    FLIP_CHECK(hipMemcpyAsync(ctx->d_counts + 1, ctx->chunk_flag + ctx->n_chunks, 4, hipMemcpyDeviceToDevice, st));
+    if (int rc = flip_copy_i32(ctx, ctx->d_counts + 1, ctx->chunk_flag + ctx->n_chunks, st)) return rc;
     // compact list of the cells that are rows of the CG system, ascending cell id
     const long long plane = (long long)ctx->g.nx * ctx->g.ny;
     const long long own_lo = ctx->slab_on ? ctx->slab_k0 * plane : 0, own_hi = ctx->slab_on ? ctx->slab_k1 * plane : ctx->B;
@@ -362,7 +362,7 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
             if (int rc = flip_exclusive_scan(ctx, ctx->cg_scan, ctx->B + 1)) return rc;
             k_compact_region_rows<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, ctx->cg_scan, ctx->mg_rows);
             FLIP_LAUNCH_CHECK();
-            FLIP_CHECK(hipMemcpyAsync(ctx->d_counts + 7, ctx->cg_scan + ctx->B, 4, hipMemcpyDeviceToDevice, st));
+            if (int rc = flip_copy_i32(ctx, ctx->d_counts + 7, ctx->cg_scan + ctx->B, st)) return rc;
         }
     }
     k_mark_cg_rows<<<flip_grid_blocks(ctx->B + 1), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan);
@@ -370,7 +370,7 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     if (int rc = flip_exclusive_scan(ctx, ctx->cg_scan, ctx->B + 1)) return rc;
     k_compact_cg_rows<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan, ctx->cg_rows);
     FLIP_LAUNCH_CHECK();
-    FLIP_CHECK(hipMemcpyAsync(ctx->d_counts + 6, ctx->cg_scan + ctx->B, 4, hipMemcpyDeviceToDevice, st));
+    if (int rc = flip_copy_i32(ctx, ctx->d_counts + 6, ctx->cg_scan + ctx->B, st)) return rc;
     // rows whose six couplings are the plain face term (1 - 0) * scale
     FLIP_CHECK(hipMemsetAsync(ctx->reg, 0, (size_t)ctx->B, st));
     ctx->reg_value = A.scale;
@@ -766,6 +766,8 @@ static void fill_pcg_args(flip_ctx *ctx, PcgArgs &A) {
     for (int a = 0; a < 6; ++a) { A.minv[a] = ctx->obj_minv[a]; A.J[a] = ctx->J[a]; }
 }
 
+__global__ void k_set_scalars(flip_pcg_scalars *dst, flip_pcg_scalars v) { *dst = v; }
+
 // flip_pcg_solve in three parts, so that flip_solve_pair can interleave two solves:
 //   pcg_prepare  validation, scalars, zeroed vectors, coarse operators, r = b, z = M^-1 r
 //   pcg_batch    `batch` iterations (direction, update, V-cycle) enqueued on ctx->stream
@@ -819,7 +821,8 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
     h.max_iter = max_iter;
     h.fused = fused ? 1 : 0;
     h.creg = ctx->reg_value;
-    FLIP_CHECK(hipMemcpyAsync(ctx->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
+    k_set_scalars<<<1, 1, 0, st>>>(ctx->scal, h); // by value: no host buffer has to outlive the call
+    FLIP_LAUNCH_CHECK();
     PcgArgs A;
     fill_pcg_args(ctx, A);
     while (ctx->events.size() < 2 + 2 * 64) {
@@ -1062,7 +1065,7 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
     };
     rc = with_system(1, [&]() -> int {
         // the row count of index_cells sits with the system that was active then
-        FLIP_CHECK(hipMemcpyAsync(ctx->d_counts, ctx->other.d_counts, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (int r = flip_copy_i32(ctx, ctx->d_counts, ctx->other.d_counts, ctx->stream)) return r;
         if (int r = flip_build_system(ctx, FLIP_SOLVE_DENSITY, dt)) return r;
         return pcg_prepare(ctx, tol, max_iter, precond, run[1], "flip_solve_pair");
     });
@@ -1280,7 +1283,8 @@ extern "C" int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, 
     h.tol2 = tol * tol;
     h.max_iter = max_iter;
     h.creg = ctx->reg_value;
-    FLIP_CHECK(hipMemcpyAsync(ctx->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
+    k_set_scalars<<<1, 1, 0, st>>>(ctx->scal, h); // by value: no host buffer has to outlive the call
+    FLIP_LAUNCH_CHECK();
     FLIP_CHECK(hipMemsetAsync(ctx->x, 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->z, 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->r, 0, (size_t)ctx->B * 8, st));

@@ -18,3 +18,6 @@ python3 $root/profiles/summarize_pmc.py $f FETCH_SIZE $out/pmc_fetch_size.csv
 python3 $root/profiles/summarize_pmc.py $w WRITE_SIZE $out/pmc_write_size.csv
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 ls $out
+# the raw traces and counter dumps are tens of MB each: only the summaries travel back
+rm -rf $out/stats $out/pmc_fetch $out/pmc_write
+ls $out
