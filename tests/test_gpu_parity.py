@@ -885,3 +885,26 @@ def test_a_context_on_a_non_blocking_stream_gives_the_same_substeps():
     a, b = results
     assert a[3] == b[3]
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("concurrent", [False, True])
+def test_iteration_cap_is_honoured_whatever_the_previous_solve_took(concurrent):
+    """The solver loop sizes its launch batches from the iteration count of the previous solve of the same kind; a cap
+    below that count must still stop the solve at the cap (Eigen's NoConvergence), and the next uncapped solve must
+    converge as before."""
+    from fluidsimulation_amd import FlipSubstep, PRECOND_MULTIGRID
+    sc = scenes.dam_break(32, ppc=4, seed=6)
+    rng = np.random.default_rng(9)
+    sc.vel = rng.normal(0, 0.3, sc.pos.shape)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        free = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, concurrent_solves=concurrent)
+        first = free.step(0.004)
+        assert first["density"]["converged"] == 1 and first["density"]["iterations"] > 8
+        capped = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, concurrent_solves=concurrent, max_iter=3)
+        info = capped.step(0.004)
+        for k in ("divergence", "density"):
+            assert info[k]["converged"] == 0 and info[k]["iterations"] == 3, (k, info[k])
+        again = free.step(0.004)
+        for k in ("divergence", "density"):
+            assert again[k]["converged"] == 1 and again[k]["rel_residual_2"] < RES_TOL, (k, again[k])
