@@ -46,10 +46,11 @@ struct alignas(64) flip_prec {
     float mass, pad0;
     double vx, vy, vz, pad1;
 };
-// The gather kernels read the sorted particles from two packed arrays of 32-byte halves instead: the position half
-// decides whether a particle lies within a cell's kernel support and carries the mass; the velocity half is read
-// only for the particles that pass.  Two consecutive slots share a 64-byte line in either array, so a lane that
-// walks a slot range pulls each line into L1 once for two particles.
+// The gather kernels read the particles in half-cell order from an array of such 64-byte records, addressed as two
+// interleaved views of 32-byte halves (record d = element 2 d of either view): the position half carries the mass, the
+// velocity half only the P2G walk reads.  Every record a walk visits lies inside the support of its cell, so P2G wants
+// both halves and finds them in one cache line.  The level-set search reads a second array of position halves alone,
+// in cell order (flip_ctx::pcell).
 struct alignas(32) flip_ppos {
     double x, y, z;
     float mass, pad0;
@@ -120,8 +121,8 @@ struct flip_ctx {
     int32_t *scan_tmp = nullptr;    // block sums of the scan
     int64_t scan_tmp_len = 0;
     double *stage = nullptr;        // [cap*3] upload/download staging (AoS)
-    flip_prec *prec = nullptr;      // [cap] x 64 bytes: flip_ppos[cap] followed by flip_pvel[cap], the gather kernels' copy,
-                                    // sorted by half cell (see k_subrow_pack)
+    flip_prec *prec = nullptr;      // [cap] x 64 bytes: position half then velocity half of each record, the gather kernels' copy,
+                                    // sorted by half cell (see k_reorder_pack)
     flip_ppos *pcell = nullptr;     // [cap] positions + mass in the primary (cell) order, for the level-set search
     int32_t *sub_start = nullptr;   // [8 B + 1] run boundaries of the half-cell order: per grid row 4 sub-rows of 2 nx
     int32_t *ls_list = nullptr;     // [B] cells left to the second pass of the level-set search (allocated on first use)

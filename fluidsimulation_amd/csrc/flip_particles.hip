@@ -248,8 +248,8 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_reorder_pack(GridDims g, const i
         flip_pvel pb;
         pb.vx = v[3]; pb.vy = v[4]; pb.vz = v[5]; pb.pad1 = 0.0;
         pcell[s] = pa;
-        pm[d] = pa;
-        pv[d] = pb;
+        pm[2 * (long long)d] = pa;   // position and velocity halves of a record sit side by side (see packed_pos)
+        pv[2 * (long long)d] = pb;
     }
 }
 // refresh of the packed records when the SoA arrays changed without a re-sort (velocities after G2P); n_inside_ptr:
@@ -266,8 +266,8 @@ __global__ void k_pack_records(long long n, const int32_t *__restrict__ n_inside
     flip_pvel b;
     b.vx = src.a[3][s]; b.vy = src.a[4][s]; b.vz = src.a[5][s]; b.pad1 = 0.0;
     const int32_t d = sub_slot[s];
-    pm[d] = a;
-    pv[d] = b;
+    pm[2 * (long long)d] = a;
+    pv[2 * (long long)d] = b;
 }
 static ParticlePtrs particle_ptrs(flip_ctx *ctx, int buffer) {
     ParticlePtrs ps;
@@ -277,8 +277,11 @@ static ParticlePtrs particle_ptrs(flip_ctx *ctx, int buffer) {
     return ps;
 }
 
+// The gathers' copy is an array of 64-byte records, position half then velocity half: record d's halves are element
+// 2 d of these two views.  Every record the P2G walk visits is inside the support, so it needs both halves, and one
+// record is one cache line access instead of two.
 static inline flip_ppos *packed_pos(flip_ctx *ctx) { return reinterpret_cast<flip_ppos *>(ctx->prec); }
-static inline flip_pvel *packed_vel(flip_ctx *ctx) { return reinterpret_cast<flip_pvel *>(reinterpret_cast<flip_ppos *>(ctx->prec) + ctx->cap); }
+static inline flip_pvel *packed_vel(flip_ctx *ctx) { return reinterpret_cast<flip_pvel *>(reinterpret_cast<flip_ppos *>(ctx->prec) + 1); }
 static inline size_t subrow_lds_bytes(const flip_ctx *ctx) { return ((size_t)8 * ctx->g.nx + 4) * sizeof(int32_t) + FLIP_ROW_QCAP * sizeof(uint16_t); }
 
 // Occupancy bands: bit0 = within 1 cell of a particle cell, bit1 = within 2 (Chebyshev distance).
@@ -531,11 +534,11 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, int nyb, cons
         int2 cur = runs[0][tid];
         unsigned feeds = ((unsigned)cur.x >> 31) | (((unsigned)cur.y >> 31) << 1);
         int32_t s = cur.x & 0x7fffffff, e = cur.y & 0x7fffffff;
-        const double2 *rec = reinterpret_cast<const double2 *>(pm + s);
+        const double2 *rec = reinterpret_cast<const double2 *>(pm + 2 * (long long)s);
         double2 p0 = rec[0], p1 = rec[1]; // (x, y) (z, mass)
         double2 q0 = make_double2(0.0, 0.0), q1 = q0;
         if (P2G) {
-            const double2 *vel = reinterpret_cast<const double2 *>(pv + s);
+            const double2 *vel = reinterpret_cast<const double2 *>(pv + 2 * (long long)s);
             q0 = vel[0]; q1 = vel[1]; // (vx, vy) (vz, -)
         }
         bool more = true;
@@ -554,10 +557,10 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, int nyb, cons
                 }
             }
             if (more) {
-                rec = reinterpret_cast<const double2 *>(pm + s);
+                rec = reinterpret_cast<const double2 *>(pm + 2 * (long long)s);
                 p0 = rec[0]; p1 = rec[1];
                 if (P2G) {
-                    const double2 *vel = reinterpret_cast<const double2 *>(pv + s);
+                    const double2 *vel = reinterpret_cast<const double2 *>(pv + 2 * (long long)s);
                     q0 = vel[0]; q1 = vel[1];
                 }
             }
