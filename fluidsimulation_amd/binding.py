@@ -58,7 +58,7 @@ PRECOND_JACOBI, PRECOND_MULTIGRID = 0, 1
 EXPORTS = [
     "flip_ctx_create", "flip_ctx_destroy", "flip_last_error", "flip_synchronize", "flip_get_desc",
     "flip_particles_upload", "flip_particles_download", "flip_particles_count", "flip_bin_particles",
-    "flip_binning_download", "flip_field_upload", "flip_field_download", "flip_field_bytes", "flip_p2g", "flip_g2p",
+    "flip_binning_download", "flip_field_upload", "flip_field_download", "flip_field_bytes", "flip_p2g", "flip_gather_stats", "flip_set_gather_mode", "flip_g2p",
     "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_fluid_levelset_from_particles", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
     "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_velocity_max_static", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_redistribute_overdense", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
@@ -98,6 +98,8 @@ def load_library(path: str = LIB_PATH):
         "flip_field_download": (C.c_int, [vp, C.c_int, vp]),
         "flip_field_bytes": (i64, [vp, C.c_int]),
         "flip_p2g": (C.c_int, [vp]),
+        "flip_gather_stats": (C.c_int, [vp, P(i64)]),
+        "flip_set_gather_mode": (C.c_int, [vp, C.c_int]),
         "flip_g2p": (C.c_int, [vp, f32]),
         "flip_apply_displacements": (C.c_int, [vp]),
         "flip_advect_particles": (C.c_int, [vp, C.c_float]),
@@ -236,6 +238,14 @@ class FlipContext:
     # ---- stages ----
     def p2g(self):
         self._check(self.lib.flip_p2g(self.h))
+
+    def gather_stats(self):
+        out = (C.c_int64 * 2)()
+        self._check(self.lib.flip_gather_stats(self.h, out))
+        return {"staged_tiles": int(out[0]), "unstaged_tiles": int(out[1])}
+
+    def set_gather_mode(self, mode: int):
+        self._check(self.lib.flip_set_gather_mode(self.h, int(mode)))
 
     def g2p(self, ratio: float):
         self._check(self.lib.flip_g2p(self.h, ratio))

@@ -157,6 +157,7 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
     dfree(c->dist_sums); dfree(c->mg_rows); dfree(c->dist_recv[0]); dfree(c->dist_recv[1]);
     if (c->dist_rw) (void)hipFree(c->dist_rw - c->pad);
     dfree(c->d_vmax);
+    dfree(c->gather_stats); dfree(c->tile_scan); dfree(c->tile_list);
     delete c;
 }
 
@@ -166,7 +167,7 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     FLIP_REQUIRE(desc->nx > 0 && desc->ny > 0 && desc->nz > 0, "flip_ctx_create: empty box");
     FLIP_REQUIRE((int64_t)desc->nx * desc->ny * desc->nz < (int64_t)2000000000, "flip_ctx_create: box too large for 32-bit cell ids");
     FLIP_REQUIRE(desc->dx > 0.f, "flip_ctx_create: dx must be positive");
-    FLIP_REQUIRE(8LL * desc->nx * 4 + 16 <= 48 * 1024, "flip_ctx_create: box too wide (nx) for the per-row half-cell index in LDS");
+    FLIP_REQUIRE(flip_subrow_lds_bytes(desc->nx) <= 64 * 1024, "flip_ctx_create: box too wide (nx > 895) for the per-row half-cell index in 64 KB of LDS");
     int ndev = 0;
     FLIP_CHECK(hipGetDeviceCount(&ndev));
     FLIP_REQUIRE(ndev > 0, "flip_ctx_create: no HIP device (this library has no CPU path)");
@@ -178,6 +179,7 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     c->B = (int64_t)desc->nx * desc->ny * desc->nz;
     c->n_chunks = flip_grid_blocks(c->B);
     c->device = device;
+    c->gather_mode = flip_default_gather_mode();
     c->stream = (hipStream_t)stream;
     const int64_t B = c->B;
 
@@ -201,6 +203,9 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     }
     A(c->cg_scan, B + 1)
     A(c->d_vmax, 3 * FLIP_MAX_PCG_BLOCKS)
+    A(c->gather_stats, 4)
+    c->n_tiles = (int64_t)((desc->nx + 3) / 4) * ((desc->ny + 3) / 4) * ((desc->nz + 3) / 4);
+    A(c->tile_scan, c->n_tiles + 1) A(c->tile_list, c->n_tiles)
 #undef A
     if (e != hipSuccess) {
         flip_ctx_destroy(c);
@@ -226,6 +231,7 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+        c->n_cu = prop.multiProcessorCount;
         int nb = prop.multiProcessorCount * 4;
         nb = (nb / 8) * 8;
         if (nb < 8) nb = 8;

@@ -127,6 +127,12 @@ struct flip_ctx {
     int32_t *sub_start = nullptr;   // [8 B + 1] run boundaries of the half-cell order: per grid row 4 sub-rows of 2 nx
     int32_t *ls_list = nullptr;     // [B] cells left to the second pass of the level-set search (allocated on first use)
     int32_t *sub_slot = nullptr;    // [cap] place of primary slot s in the half-cell order
+    int64_t n_tiles = 0;            // 4 x 4 x 4-cell tiles of the box (the LDS-staged gather's work units)
+    int32_t *tile_scan = nullptr;   // [n_tiles + 1] flags, then their exclusive scan; [n_tiles] = tiles that hold a band cell
+    int32_t *tile_list = nullptr;   // [n_tiles] those tiles, ascending
+    int n_cu = 256;                 // compute units of the device
+    int gather_mode = 0;            // 0: k_gather (per-lane walk of global memory), 1: k_gather_tile (LDS-staged)
+    int32_t *gather_stats = nullptr; // [4] tiles of the LDS-staged gather since creation: 0 staged, 1 walked from global memory (too crowded)
     bool prec_valid = false;
     bool binned = false;
     bool slots_valid = false;       // cell_start still describes the slot order (no upload / exchange since the sort)
@@ -224,6 +230,7 @@ struct flip_ctx {
     double *dist_rw = nullptr;      // weighted copy of the residual, the V-cycle's right-hand side when slab_weighted
 };
 
+int flip_default_gather_mode();            // FLIP_GATHER_TILE
 int flip_alloc_system(flip_ctx *ctx);      // the active system's arrays (used for both sets)
 void flip_free_system(flip_ctx *ctx);
 void flip_swap_systems(flip_ctx *ctx);     // active <-> other
@@ -254,6 +261,11 @@ int flip_fail_hip(flip_ctx *ctx, hipError_t e, const char *what, const char *fil
         if (!(cond)) return flip_fail(ctx, msg, __FILE__, __LINE__);            \
     } while (0)
 #define FLIP_LAUNCH_CHECK() FLIP_CHECK(hipGetLastError())
+
+// Dynamic LDS of the per-row reordering kernel (k_reorder_pack): 8 nx half-cell counters + 4 wave totals, and the upload
+// index (32 bit) and half-cell number (16 bit) of up to FLIP_ROW_QCAP particles of the row.
+#define FLIP_ROW_QCAP 6144
+static inline size_t flip_subrow_lds_bytes(int nx) { return ((size_t)8 * nx + 4) * sizeof(int32_t) + FLIP_ROW_QCAP * (sizeof(int32_t) + sizeof(uint16_t)); }
 
 static inline int flip_grid_blocks(int64_t n) { return (int)((n + FLIP_BLOCK - 1) / FLIP_BLOCK); }
 

@@ -57,59 +57,6 @@ __global__ void k_scatter_slots(long long n, const int32_t *__restrict__ cell_id
     slot_key[slot] = pid[s];
 }
 
-// max-heap sift of (key, src) pairs within [0, lim)
-__device__ void d_sift_down(int32_t *key, int32_t *src, int32_t root, int32_t lim) {
-    const int32_t rk = key[root], rs = src[root];
-    int32_t hole = root;
-    for (;;) {
-        int32_t child = 2 * hole + 1;
-        if (child >= lim) break;
-        if (child + 1 < lim && key[child + 1] > key[child]) ++child;
-        if (key[child] <= rk) break;
-        key[hole] = key[child];
-        src[hole] = src[child];
-        hole = child;
-    }
-    key[hole] = rk;
-    src[hole] = rs;
-}
-
-// The atomic ranks above depend on timing; sorting each cell's slots by upload index makes the final
-// order the stable one.  One thread per cell: insertion sort (cells hold a handful of particles),
-// heapsort for a crowded cell.  The bin of the outside particles is left unsorted (the host passes
-// n_bins = B): its order affects nothing, and it may be large.
-__global__ void k_sort_cells(long long n_bins, const int32_t *__restrict__ cell_start, int32_t *__restrict__ slot_src,
-                             int32_t *__restrict__ slot_key) {
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_bins) return;
-    const int32_t b = cell_start[c], e = cell_start[c + 1];
-    const int32_t m = e - b;
-    if (m < 2) return;
-    if (m > 48) {
-        // crowded cell: in-place heapsort keeps the work at m log m for one thread
-        int32_t *key = slot_key + b, *src = slot_src + b;
-        for (int32_t root = m / 2 - 1; root >= 0; --root) d_sift_down(key, src, root, m);
-        for (int32_t end = m - 1; end > 0; --end) {
-            const int32_t tk = key[0], ts = src[0];
-            key[0] = key[end]; src[0] = src[end];
-            key[end] = tk; src[end] = ts;
-            d_sift_down(key, src, 0, end);
-        }
-        return;
-    }
-    for (int32_t a = b + 1; a < e; ++a) {
-        const int32_t key = slot_key[a], src = slot_src[a];
-        int32_t q = a - 1;
-        while (q >= b && slot_key[q] > key) {
-            slot_key[q + 1] = slot_key[q];
-            slot_src[q + 1] = slot_src[q];
-            --q;
-        }
-        slot_key[q + 1] = key;
-        slot_src[q + 1] = src;
-    }
-}
-
 struct ParticlePtrs {
     double *a[6];
     float *mass;
@@ -154,21 +101,23 @@ __device__ __forceinline__ int d_sub_index(const GridDims &g, double x, double y
     return (hz * 2 + hy) * (2 * g.nx) + 2 * ci + hx;
 }
 
-// One workgroup per grid row (j, k) does the whole reordering of the row's particles: it gathers them from the previous
-// order (slot_src), counts them per half cell in LDS, scans, writes the row's 8 nx entries of sub_start, and stores every
-// particle three times -- SoA in the primary (cell, upload index) order, the position record of that order, and the
-// position and velocity records in the half-cell order.  The rank of a particle inside its half cell is the number of
-// earlier slots of its cell that fall into the same half cell (the cell's slots are sorted by upload index, so the
-// half-cell order is too); the half-cell numbers of the row are parked in LDS for that count (rows too crowded for
-// it use a scratch array in global memory).
-#define FLIP_ROW_QCAP 6144
+// One workgroup per grid row (j, k) does the whole reordering of the row's particles.  The counting sort left every cell's
+// particles in its slot range in the order of arrival (atomic ranks, which depend on timing); here every particle finds its
+// final place by counting, among the particles of its cell, those with a smaller upload index -- that makes the order the
+// stable one -- and, among those, the ones in its own half cell, which is its rank in the half-cell order.  The upload
+// indices and half-cell numbers of the row are parked in LDS for those counts (a row too crowded for that reads them
+// from global memory).  The workgroup gathers the row's particles from the previous order (slot_src), counts them per
+// half cell in LDS, scans, writes the row's 8 nx entries of sub_start, and stores every particle three times -- SoA in the
+// primary (cell, upload index) order, the position record of that order, and the position and velocity records in the
+// half-cell order.
 __global__ void __launch_bounds__(FLIP_BLOCK) k_reorder_pack(GridDims g, const int32_t *__restrict__ cell_start,
                                                             const int32_t *__restrict__ slot_src, const int32_t *__restrict__ slot_key,
                                                             ParticlePtrs src, ParticlePtrs dst, int32_t *__restrict__ sub_start,
                                                             int32_t *__restrict__ sub_slot, int32_t *__restrict__ tmp_q,
                                                             flip_ppos *__restrict__ pcell, flip_ppos *__restrict__ pm,
                                                             flip_pvel *__restrict__ pv) {
-    extern __shared__ int32_t lds[]; // [8 nx] counts, then exclusive offsets; [4] wave totals; [FLIP_ROW_QCAP / 2] half-cell numbers (16 bit)
+    extern __shared__ __align__(16) int32_t lds_words[];
+    int32_t *lds = lds_words; // [8 nx] counts, then exclusive offsets; [4] wave totals; [FLIP_ROW_QCAP] upload indices; [FLIP_ROW_QCAP / 2] half-cell numbers (16 bit)
     const int nsub = 8 * g.nx;
     const long long row = blockIdx.x;
     const long long c0 = row * g.nx;
@@ -182,7 +131,8 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_reorder_pack(GridDims g, const i
         return;
     }
     for (int q = tid; q < nsub; q += FLIP_BLOCK) lds[q] = 0;
-    uint16_t *qbuf = reinterpret_cast<uint16_t *>(lds + nsub + 4);
+    int32_t *kbuf = lds + nsub + 4;
+    uint16_t *qbuf = reinterpret_cast<uint16_t *>(kbuf + FLIP_ROW_QCAP);
     const bool in_lds = r1 - r0 <= FLIP_ROW_QCAP; // uniform over the workgroup
     __syncthreads();
     const int j = (int)(row % g.ny), k = (int)(row / g.ny);
@@ -192,7 +142,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_reorder_pack(GridDims g, const i
         const int ci = (int)floor(x + 0.5) - g.ox;
         const int q = d_sub_index(g, x, y, z, ci, j, k);
         atomicAdd(&lds[q], 1); // integer: the totals do not depend on the order of arrival
-        if (in_lds) qbuf[s - r0] = (uint16_t)q;
+        if (in_lds) { qbuf[s - r0] = (uint16_t)q; kbuf[s - r0] = slot_key[s]; }
         else tmp_q[s] = q;
     }
     __syncthreads();
@@ -221,27 +171,39 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_reorder_pack(GridDims g, const i
     __syncthreads();
     for (int q = tid; q < nsub; q += FLIP_BLOCK) out[q] = lds[q];
     if (last && tid == 0) out[nsub] = r1;
-    for (int32_t s = r0 + tid; s < r1; s += FLIP_BLOCK) {
-        const int32_t o = slot_src[s];
+    for (int32_t sa = r0 + tid; sa < r1; sa += FLIP_BLOCK) {
+        const int32_t o = slot_src[sa];
         double v[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) v[a] = src.a[a][o];
         const float m = src.mass[o];
         const int ci = (int)floor(v[0] + 0.5) - g.ox;
-        const int32_t cs = cell_start[c0 + ci];
-        int q, rank = 0;
+        const int32_t cs = cell_start[c0 + ci], ce = cell_start[c0 + ci + 1];
+        int q, rank_cell = 0, rank_sub = 0;
+        int32_t key;
         if (in_lds) {
-            q = qbuf[s - r0];
-            for (int32_t t = cs; t < s; ++t) rank += qbuf[t - r0] == q ? 1 : 0;
+            q = qbuf[sa - r0];
+            key = kbuf[sa - r0];
+            for (int32_t t = cs - r0; t < ce - r0; ++t) {
+                const int less = kbuf[t] < key ? 1 : 0;
+                rank_cell += less;
+                rank_sub += (qbuf[t] == q) ? less : 0;
+            }
         } else {
-            q = tmp_q[s];
-            for (int32_t t = cs; t < s; ++t) rank += tmp_q[t] == q ? 1 : 0;
+            q = tmp_q[sa];
+            key = slot_key[sa];
+            for (int32_t t = cs; t < ce; ++t) {
+                const int less = slot_key[t] < key ? 1 : 0;
+                rank_cell += less;
+                rank_sub += (tmp_q[t] == q) ? less : 0;
+            }
         }
-        const int32_t d = lds[q] + rank;
+        const int32_t s = cs + rank_cell;  // place in the primary order
+        const int32_t d = lds[q] + rank_sub; // place in the half-cell order
 #pragma unroll
         for (int a = 0; a < 6; ++a) dst.a[a][s] = v[a];
         dst.mass[s] = m;
-        dst.pid[s] = slot_key[s];
+        dst.pid[s] = key;
         sub_slot[s] = d;
         flip_ppos pa;
         pa.x = v[0]; pa.y = v[1]; pa.z = v[2]; pa.mass = m; pa.pad0 = 0.f;
@@ -282,7 +244,7 @@ static ParticlePtrs particle_ptrs(flip_ctx *ctx, int buffer) {
 // record is one cache line access instead of two.
 static inline flip_ppos *packed_pos(flip_ctx *ctx) { return reinterpret_cast<flip_ppos *>(ctx->prec); }
 static inline flip_pvel *packed_vel(flip_ctx *ctx) { return reinterpret_cast<flip_pvel *>(reinterpret_cast<flip_ppos *>(ctx->prec) + 1); }
-static inline size_t subrow_lds_bytes(const flip_ctx *ctx) { return ((size_t)8 * ctx->g.nx + 4) * sizeof(int32_t) + FLIP_ROW_QCAP * sizeof(uint16_t); }
+static inline size_t subrow_lds_bytes(const flip_ctx *ctx) { return flip_subrow_lds_bytes(ctx->g.nx); }
 
 // Occupancy bands: bit0 = within 1 cell of a particle cell, bit1 = within 2 (Chebyshev distance).
 // Box dilation is separable: one pass per axis.
@@ -319,6 +281,30 @@ __global__ void k_band_axis(GridDims g, int axis, const uint8_t *__restrict__ in
     out[c] = m;
 }
 
+#define GT_T 4 // edge of the LDS-staged gather's tiles in cells (see k_gather_tile)
+// tiles with a cell of the band (bit 1): flag, then compacted by a scan into the list the gather's workgroups share out
+__global__ void k_gather_tile_flags(GridDims g, int tiles_x, int tiles_y, long long ntiles, const uint8_t *__restrict__ band,
+                                    int32_t *__restrict__ flag) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > ntiles) return;
+    if (t == ntiles) { flag[t] = 0; return; } // terminator of the scan
+    const int i0 = (int)(t % tiles_x) * GT_T;
+    const long long tq = t / tiles_x;
+    const int j0 = (int)(tq % tiles_y) * GT_T, k0 = (int)(tq / tiles_y) * GT_T;
+    int any = 0;
+    for (int dk = 0; dk < GT_T && k0 + dk < g.nz; ++dk)
+        for (int dj = 0; dj < GT_T && j0 + dj < g.ny; ++dj) {
+            const long long row = d_lid(g, 0, j0 + dj, k0 + dk);
+            for (int di = 0; di < GT_T && i0 + di < g.nx; ++di) any |= band[row + i0 + di] & 2;
+        }
+    flag[t] = any ? 1 : 0;
+}
+__global__ void k_gather_tile_list(long long ntiles, const int32_t *__restrict__ scan, int32_t *__restrict__ list) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    if (scan[t + 1] > scan[t]) list[scan[t]] = (int32_t)t;
+}
+
 extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
     FLIP_REQUIRE(ctx, "null context");
     FLIP_CHECK(hipSetDevice(ctx->device));
@@ -349,8 +335,6 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
         k_scatter_slots<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->cell_id, ctx->pid[src], ctx->cell_start,
                                                                    ctx->cell_fill, ctx->slot_src, ctx->slot_key);
         FLIP_LAUNCH_CHECK();
-        k_sort_cells<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(B, ctx->cell_start, ctx->slot_src, ctx->slot_key);
-        FLIP_LAUNCH_CHECK();
         ctx->cur = dst;
     }
     // every grid row gathers its particles from the previous order and stores them in both orders (also with no particles:
@@ -371,6 +355,14 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
     FLIP_LAUNCH_CHECK();
     k_band_axis<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, 2, ctx->tmp_u8, ctx->band);
     FLIP_LAUNCH_CHECK();
+    {   // the tiles of the LDS-staged gather that hold a cell of the band
+        const int tx = (ctx->g.nx + GT_T - 1) / GT_T, ty = (ctx->g.ny + GT_T - 1) / GT_T;
+        k_gather_tile_flags<<<flip_grid_blocks(ctx->n_tiles + 1), FLIP_BLOCK, 0, st>>>(g, tx, ty, ctx->n_tiles, ctx->band, ctx->tile_scan);
+        FLIP_LAUNCH_CHECK();
+        if (int rc = flip_exclusive_scan(ctx, ctx->tile_scan, ctx->n_tiles + 1)) return rc;
+        k_gather_tile_list<<<flip_grid_blocks(ctx->n_tiles), FLIP_BLOCK, 0, st>>>(ctx->n_tiles, ctx->tile_scan, ctx->tile_list);
+        FLIP_LAUNCH_CHECK();
+    }
     ctx->binned = true;
     ctx->slots_valid = true;
     if (n_outside) {
@@ -613,15 +605,482 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, int nyb, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-staged form of the gather (the default).  A workgroup owns a tile of 4 x 4 x 4 cells.  The support of the tile
+// is 10 x 10 (z, y) half-cell rows, and within each of them ONE contiguous span of the half-cell order (the half cells
+// 2 i0 - 1 .. 2 i0 + 8 of that sub-row): the workgroup copies those 100 spans into LDS with coalesced 16-byte loads
+// -- every record once per tile instead of once per cell and lane -- as separate arrays x[], y[], z[], vx[], vy[],
+// vz[] (8-byte elements, so that neighbouring lanes, which read neighbouring records, fall on different banks) and
+// mass[].  Every cell then meets its records in the order stated at d_upper_half, run by run, exactly as k_gather
+// does from global memory, so the sums are the same bit for bit; the LDS positions of a cell's records are written
+// once into a per-cell list (16-bit entries), so that the walk itself is a plain counted loop.
+// The four sums of a cell (u, v, w of P2G and the density) are independent chains over the same records: the four
+// waves of the workgroup each take one of them for the tile's 64 cells (wave 0: u, 1: v, 2: w, 3: density).  That
+// repeats the three differences and the loop control but gives the CU four times the waves per LDS byte, and LDS
+// capacity (two tiles per CU), not arithmetic, limits the number of tiles in flight.
+// The workgroups are persistent and share out the list of tiles that hold a cell of the band (built by the binning).
+// A tile whose spans hold more than GT_CAP records, or a cell more than GT_LMAX (a crowded corner of the scene), walks
+// global memory instead, run by run as k_gather does.
+#define GT_CELLS (GT_T * GT_T * GT_T)        // 64 = one wave
+#define GT_HR (2 * GT_T + 2)                 // half-cell rows of a tile's support per axis
+#define GT_NSPAN (GT_HR * GT_HR)
+#define GT_SST (2 * GT_T + 3)                // boundaries of the 2 T + 2 half cells of a span
+#define GT_CAP 1152                          // records a tile can stage (about 1000 at 8 particles per cell)
+#define GT_STRIDE (GT_CAP + 4)               // elements between the arrays: a quarter of the banks apart
+#define GT_LMAX 120                          // records a cell can list (64 at 8 particles per cell)
+#define GT_SPG ((GT_NSPAN + 15) / 16)        // spans per 16-lane group of the staging copy
+template <bool P2G>
+struct GatherTileLds {
+    static constexpr int NARR = P2G ? 6 : 3;
+    static constexpr size_t rec = 0;                                        // double [NARR][GT_STRIDE]; unstaged tiles: int2 runs[16][64]
+    static constexpr size_t mass = rec + (size_t)NARR * GT_STRIDE * 8;      // float [GT_CAP]
+    static constexpr size_t idx = mass + (size_t)GT_CAP * 4;                // uint16 [GT_LMAX][64]: LDS position of a cell's t-th record
+    static constexpr size_t sst = idx + (size_t)GT_LMAX * GT_CELLS * 2;     // int32 [GT_NSPAN][GT_SST]
+    static constexpr size_t off = sst + (size_t)GT_NSPAN * GT_SST * 4;      // int32 [128]: exclusive scan of the span lengths
+    static constexpr size_t total = off + 128 * 4;
+};
+static_assert(GT_NSPAN <= 128 && GT_CAP < 65536 && 3 * GT_STRIDE * 8 >= 16 * GT_CELLS * 8, "tile tables");
+
+// One record of the walk: position, and the role's fourth value (a velocity component; the mass as float).
+template <int ROLE, bool STAGED, bool P2G>
+__device__ __forceinline__ void d_gt_fetch(const char *lds, const double *__restrict__ prec, int32_t s, double &x, double &y, double &z, double &q,
+                                           float &m) {
+    if (STAGED) {
+        const double *r = reinterpret_cast<const double *>(lds + GatherTileLds<P2G>::rec);
+        x = r[s]; y = r[GT_STRIDE + s]; z = r[2 * GT_STRIDE + s];
+        if (ROLE < 3) q = r[(3 + (ROLE < 3 ? ROLE : 0)) * GT_STRIDE + s];
+        else m = reinterpret_cast<const float *>(lds + GatherTileLds<P2G>::mass)[s];
+    } else {
+        const double *r = prec + 8 * (long long)s;
+        x = r[0]; y = r[1]; z = r[2];
+        if (ROLE < 3) q = r[4 + (ROLE < 3 ? ROLE : 0)];
+        else m = __int_as_float((int)(__double_as_longlong(r[3]) & 0xffffffffLL));
+    }
+}
+// The contribution of one record to one role's sums.  ROLE 0..2: ws += w_c, acc += w_c v_c (src/Functors.cpp:37-40
+// with the weights of src/FluidSimulator.cpp:1361-1371); ROLE 3: the density sum (src/Functors.cpp:252-258).  Adding
+// a zero weight leaves both sums unchanged, so the reference's "skip if the weight is zero" needs no test here.
+template <int ROLE>
+__device__ __forceinline__ void d_gt_add(double rx, double ry, double rz, double rq, float rm, double cx, double cy, double cz, double denom,
+                                         double rden, double &ws, double &acc, float &dens) {
+    const double d0 = rx - cx, d1 = ry - cy, d2 = rz - cz;
+    if (ROLE == 3) {
+        const double wgt = d_hat_in(d0) * d_hat_in(d1) * d_hat_in(d2);
+        if (wgt > 0) {
+            const double a = wgt * (double)rm;
+            const double qa = a * rden;
+            const double quot = fma(fma(-qa, denom, a), rden, qa); // = a / denom, correctly rounded (see k_gather)
+            const double add = (double)0.f + quot;
+            dens = (float)((double)dens + add);
+        }
+    } else {
+        const float fx = ROLE == 0 ? (float)d_hat_up(d0 + 0.5) : (float)d_hat_in(d0);
+        const float fy = ROLE == 1 ? (float)d_hat_up(d1 + 0.5) : (float)d_hat_in(d1);
+        const float fz = ROLE == 2 ? (float)d_hat_up(d2 + 0.5) : (float)d_hat_in(d2);
+        const double wc = (double)(fx * fy * fz);
+        ws = ws + wc;
+        acc = acc + wc * rq;
+    }
+}
+// Staged walk: the cell's records by its list; the list entry is requested two records ahead, the record one ahead.
+template <int ROLE, bool P2G>
+__device__ __forceinline__ void d_gt_walk_list(const char *lds, int lane, int total, double cx, double cy, double cz, double denom, double rden,
+                                               double &ws, double &acc, float &dens) {
+    if (total <= 0) return;
+    const uint16_t *il = reinterpret_cast<const uint16_t *>(lds + GatherTileLds<P2G>::idx) + lane;
+    const int last = total - 1;
+    double x, y, z, q = 0.0;
+    float m = 0.f;
+    d_gt_fetch<ROLE, true, P2G>(lds, nullptr, il[0], x, y, z, q, m);
+    int ib = il[(last < 1 ? last : 1) * GT_CELLS];
+    for (int t = 0; t < total; ++t) {
+        const double rx = x, ry = y, rz = z, rq = q;
+        const float rm = m;
+        const int t2 = t + 2 < last ? t + 2 : last;
+        const int ic = il[t2 * GT_CELLS];
+        d_gt_fetch<ROLE, true, P2G>(lds, nullptr, ib, x, y, z, q, m); // past the end: the last record again, not used
+        ib = ic;
+        d_gt_add<ROLE>(rx, ry, rz, rq, rm, cx, cy, cz, denom, rden, ws, acc, dens);
+    }
+}
+// Unstaged walk: the non-empty runs (first, end) of the cell in global record numbers, parked in LDS.
+template <int ROLE, bool P2G>
+__device__ __forceinline__ void d_gt_walk_runs(const char *lds, const double *__restrict__ prec, int lane, int nr, double cx, double cy, double cz,
+                                               double denom, double rden, double &ws, double &acc, float &dens) {
+    if (nr <= 0) return;
+    const int2 *runs = reinterpret_cast<const int2 *>(lds + GatherTileLds<P2G>::rec) + lane;
+    int2 cur = runs[0];
+    int32_t s = cur.x, e = cur.y;
+    double x, y, z, q = 0.0;
+    float m = 0.f;
+    d_gt_fetch<ROLE, false, P2G>(lds, prec, s, x, y, z, q, m);
+    int ri = 0;
+    bool more = true;
+    while (more) {
+        const double rx = x, ry = y, rz = z, rq = q;
+        const float rm = m;
+        ++s;
+        if (s == e) {
+            ++ri;
+            more = ri < nr;
+            if (more) { cur = runs[ri * GT_CELLS]; s = cur.x; e = cur.y; }
+        }
+        if (more) d_gt_fetch<ROLE, false, P2G>(lds, prec, s, x, y, z, q, m);
+        d_gt_add<ROLE>(rx, ry, rz, rq, rm, cx, cy, cz, denom, rden, ws, acc, dens);
+    }
+}
+
+template <int ROLE, bool P2G>
+__device__ __forceinline__ void d_gt_role(const char *lds, const double *__restrict__ prec, bool staged, const GridDims &g, int lane, int count,
+                                          bool live, int i, int j, int k, long long c, float fw, double *__restrict__ out,
+                                          uint8_t *__restrict__ active, const DensityArgs &da) {
+    if (!live) return;
+    const double cx = (double)(g.ox + i), cy = (double)(g.oy + j), cz = (double)(g.oz + k);
+    double ws = (double)10e-37f, acc = 0.0; // background of the weight grid (src/FluidSimulator.cpp:32,77)
+    float dens = 0.f;
+    double denom = 1.0, rden = 1.0;
+    if (ROLE == 3) {
+        denom = (double)(fw / 6) * da.vs3;
+        if (fw > 0) rden = 1.0 / denom;
+        else count = 0; // no density term without a liquid fraction (src/Functors.cpp:240)
+    }
+    if (staged) d_gt_walk_list<ROLE, P2G>(lds, lane, count, cx, cy, cz, denom, rden, ws, acc, dens);
+    else d_gt_walk_runs<ROLE, P2G>(lds, prec, lane, count, cx, cy, cz, denom, rden, ws, acc, dens);
+    if (ROLE == 3) {
+        float dn = dens;
+        if (0 < fw && fw < 6) dn = dn > da.rest ? dn : da.rest;
+        da.density[c] = dn;
+        if ((double)dn > 1.5 * (double)da.rest) atomicAdd(da.n_over, 1);
+    } else {
+        out[c] = acc / ws;
+        if (ROLE == 2) active[c] = 1;
+    }
+}
+
+// Run r of a cell (the order (z cell, y cell, z half, y half) of the walk) lies in the half-cell row 2 iz + zoff(r) of the
+// tile's support in z and 2 iy + yoff(r) in y; two bits per run.
+__device__ __forceinline__ int d_gt_zoff(int r) { return (int)((0xFF9A5900u >> (2 * r)) & 3u); } // 0 0 0 0 1 2 1 1 2 2 1 2 3 3 3 3
+__device__ __forceinline__ int d_gt_yoff(int r) { return (int)((0xE4F990E4u >> (2 * r)) & 3u); } // 0 1 2 3 0 0 1 2 1 2 3 3 0 1 2 3
+// one 16-byte piece of a record into the staged arrays
+template <bool P2G>
+__device__ __forceinline__ void d_gt_store(double *rec, float *mass, int d, int part, double2 t) {
+    if (part == 0) { rec[d] = t.x; rec[GT_STRIDE + d] = t.y; }
+    else if (part == 1) { rec[2 * GT_STRIDE + d] = t.x; mass[d] = __int_as_float((int)(__double_as_longlong(t.y) & 0xffffffffLL)); }
+    else if (P2G && part == 2) { rec[3 * GT_STRIDE + d] = t.x; rec[4 * GT_STRIDE + d] = t.y; }
+    else if (P2G) rec[5 * GT_STRIDE + d] = t.x;
+}
+// What the stages of one tile hand on to the next ones (per lane: the lane's cell).
+struct GtTile {
+    int id;        // tile number, -1: none
+    int flags;     // bit 0: the cell is in the band, bit 1: the tile's records are staged in LDS
+    float fw;      // sum of the six liquid fractions around the cell (density role)
+    int count;     // records of the cell (staged) or non-empty runs (unstaged)
+    int pos0;      // records of the cell before the four runs this wave lists
+};
+// Loads of a tile's first stage, in flight while the previous tile is walked.
+struct GtPre {
+    int32_t sv[(GT_NSPAN * GT_SST + 255) / 256];
+    float phi[7];
+    int32_t bnd;
+};
+
+// The workgroup is a pipeline over its tiles: while tile n is walked (arithmetic on LDS), the copies of tile n + 1's
+// records are on their way from memory into registers, and so are the span boundaries, band byte and level-set
+// values of tile n + 2.  Per tile that leaves the LDS writes, three barriers and the walk on the critical path.
+template <bool P2G>
+__global__ void __launch_bounds__(256, 2) k_gather_tile(GridDims g, int tiles_x, int tiles_y, const int32_t *__restrict__ tile_list,
+                                                        const int32_t *__restrict__ n_tiles_ptr, const int32_t *__restrict__ sub_start,
+                                                        const uint8_t *__restrict__ band, const double *__restrict__ prec, double *__restrict__ u,
+                                                        double *__restrict__ v, double *__restrict__ w, uint8_t *__restrict__ active, DensityArgs da,
+                                                        int32_t *__restrict__ stats) {
+    using L = GatherTileLds<P2G>;
+    extern __shared__ __align__(16) int32_t lds_words[]; // one name and type for the dynamic LDS of this file
+    char *lds = reinterpret_cast<char *>(lds_words);
+    constexpr int NT = 256, NSV = (GT_NSPAN * GT_SST + NT - 1) / NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = P2G ? wave : 3;
+    const bool walker = P2G || wave == 0; // density alone: one wave walks, the others only help to stage
+    const int ix = lane & (GT_T - 1), iy = (lane / GT_T) & (GT_T - 1), iz = lane / (GT_T * GT_T);
+    int32_t *sst = reinterpret_cast<int32_t *>(lds + L::sst);
+    int32_t *soff = reinterpret_cast<int32_t *>(lds + L::off);
+    double *rec = reinterpret_cast<double *>(lds + L::rec);
+    float *mass = reinterpret_cast<float *>(lds + L::mass);
+    const double2 *__restrict__ src = reinterpret_cast<const double2 *>(prec);
+    const int nx2 = 2 * g.nx;
+    const int gq = tid >> 4, rsub = (tid >> 2) & 3, part = tid & 3; // the copy: a 16-lane group per span, 4 records x 4 pieces per step
+    const bool wanted = P2G || part < 2;
+    // consecutive workgroups go to the eight XCDs in turn: every XCD gets one contiguous piece of the list (tiles in the
+    // order x, y, z), so that tiles which share spans meet in the same L2
+    const int n_live = *n_tiles_ptr;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+    const int t_lo = (int)((long long)n_live * xcd / 8), t_hi = (int)((long long)n_live * (xcd + 1) / 8);
+    int tt = t_lo + (int)(blockIdx.x >> 3);
+    int id0 = tt < t_hi ? tile_list[tt] : -1;
+    if (id0 < 0) return;
+    int id1 = tt + per_xcd < t_hi ? tile_list[tt + per_xcd] : -1;
+    int id2 = tt + 2 * per_xcd < t_hi ? tile_list[tt + 2 * per_xcd] : -1;
+    tt += 3 * per_xcd;
+    int n_unstaged = 0, n_staged = 0;
+
+    // stage 1: everything a tile needs from global memory before its copy can be addressed
+    auto issue_pre = [&](int id, GtPre &p) {
+        const int tix = id % tiles_x, tq = id / tiles_x;
+        const int i0 = tix * GT_T, j0 = (tq % tiles_y) * GT_T, k0 = (tq / tiles_y) * GT_T;
+        const int i = i0 + ix, j = j0 + iy, k = k0 + iz;
+        const bool inside = i < g.nx && j < g.ny && k < g.nz;
+        const long long c = inside ? d_lid(g, i, j, k) : 0;
+        p.bnd = inside ? (int32_t)band[c] : 0;
+#pragma unroll
+        for (int a = 0; a < NSV; ++a) {
+            int q = tid + a * NT;
+            asm volatile("" : "+v"(q)); // keeps the index arithmetic below inside the loop (hoisted, it holds thirty registers per lane)
+            int32_t val = 0;
+            if (q < GT_NSPAN * GT_SST) {
+                // boundaries of the half cells of every span (clamped to the row; rows outside the box are empty)
+                const int span = q / GT_SST, e = q - span * GT_SST;
+                const int zh = span / GT_HR, yh = span - zh * GT_HR;
+                const int kk = k0 - 1 + ((zh + 1) >> 1), hz = (zh + 1) & 1;
+                const int jj = j0 - 1 + ((yh + 1) >> 1), hy = (yh + 1) & 1;
+                if (kk >= 0 && kk < g.nz && jj >= 0 && jj < g.ny) {
+                    int hc = 2 * i0 - 1 + e;
+                    hc = hc < 0 ? 0 : (hc > nx2 ? nx2 : hc);
+                    val = sub_start[((long long)kk * g.ny + jj) * (4LL * nx2) + (long long)(hz * 2 + hy) * nx2 + hc];
+                }
+            }
+            p.sv[a] = val;
+        }
+        if (role == 3 && walker) {
+            const float *__restrict__ phi = da.phi;
+            p.phi[0] = inside ? phi[c] : 0.f;
+            p.phi[1] = inside ? d_getf(g, phi, i - 1, j, k, da.phi_bg) : 0.f;
+            p.phi[2] = inside ? d_getf(g, phi, i, j - 1, k, da.phi_bg) : 0.f;
+            p.phi[3] = inside ? d_getf(g, phi, i, j, k - 1, da.phi_bg) : 0.f;
+            p.phi[4] = inside ? d_getf(g, phi, i + 1, j, k, da.phi_bg) : 0.f;
+            p.phi[5] = inside ? d_getf(g, phi, i, j + 1, k, da.phi_bg) : 0.f;
+            p.phi[6] = inside ? d_getf(g, phi, i, j, k + 1, da.phi_bg) : 0.f;
+        }
+    };
+    auto write_sst = [&](const GtPre &p) {
+#pragma unroll
+        for (int a = 0; a < NSV; ++a)
+            if (tid + a * NT < GT_NSPAN * GT_SST) sst[tid + a * NT] = p.sv[a];
+    };
+    // stage 2 (the span boundaries are in LDS): scan of the span lengths -- every wave for itself, all write the same values
+    // --, the lane's cell and its record count
+    auto setup = [&](int id, const GtPre &p, GtTile &t) {
+        t.id = id;
+        const int tix = id % tiles_x, tq = id / tiles_x;
+        const int i = tix * GT_T + ix, j = (tq % tiles_y) * GT_T + iy, k = (tq / tiles_y) * GT_T + iz;
+        const bool inside = i < g.nx && j < g.ny && k < g.nz;
+        const long long c = inside ? d_lid(g, i, j, k) : 0;
+        const bool live = (p.bnd & 2) != 0;
+        t.fw = 0.f;
+        if (role == 3 && walker)
+            t.fw = d_frac2(p.phi[1], p.phi[0]) + d_frac2(p.phi[2], p.phi[0]) + d_frac2(p.phi[3], p.phi[0]) + d_frac2(p.phi[4], p.phi[0])
+                   + d_frac2(p.phi[5], p.phi[0]) + d_frac2(p.phi[6], p.phi[0]);
+        if (inside && !live && walker) {
+            if (P2G && role == 0) u[c] = 0.0;
+            if (P2G && role == 1) v[c] = 0.0;
+            if (P2G && role == 2) { w[c] = 0.0; active[c] = 0; }
+            if (role == 3) da.density[c] = 0.f;
+        }
+        const int sa = 2 * lane, sb = 2 * lane + 1;
+        const int32_t la = sa < GT_NSPAN ? sst[sa * GT_SST + GT_SST - 1] - sst[sa * GT_SST] : 0;
+        const int32_t lb = sb < GT_NSPAN ? sst[sb * GT_SST + GT_SST - 1] - sst[sb * GT_SST] : 0;
+        int32_t incl = la + lb;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t x = __shfl_up(incl, off, FLIP_WAVE);
+            if (lane >= off) incl += x;
+        }
+        if (sb <= GT_NSPAN) { soff[sa] = incl - (la + lb); soff[sb] = incl - lb; }
+        const int32_t R = __shfl(incl, 63, FLIP_WAVE);
+        {   // the lowest record number among the non-empty spans (the base of the copy's addresses)
+            int32_t lo = 0x7fffffff;
+            if (la > 0) lo = sst[sa * GT_SST];
+            if (lb > 0) { const int32_t q = sst[sb * GT_SST]; lo = q < lo ? q : lo; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const int32_t q = __shfl_xor(lo, off, FLIP_WAVE); lo = q < lo ? q : lo; }
+            if (lane == 0) { soff[GT_NSPAN + 4] = lo == 0x7fffffff ? 0 : lo; soff[GT_NSPAN + 5] = 0; }
+        }
+        // the 16 runs of the cell in the order (z cell, y cell, z half, y half): total length, and the part of it that lies
+        // before the four runs this wave will list
+        t.count = 0; t.pos0 = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int span = (2 * iz + d_gt_zoff(r)) * GT_HR + 2 * iy + d_gt_yoff(r);
+            const int32_t len = live ? sst[span * GT_SST + 2 * ix + 4] - sst[span * GT_SST + 2 * ix] : 0;
+            t.count += len;
+            if ((r >> 2) < wave) t.pos0 += len;
+        }
+        const bool staged = R <= GT_CAP && !__any(t.count > GT_LMAX); // the same in every wave: lanes are cells
+        t.flags = (live ? 1 : 0) | (staged ? 2 : 0);
+    };
+    // stage 3a: request the copy (x y | z mass | vx vy | vz - : a 16-byte piece per lane)
+    auto issue_stage = [&](const GtTile &t, double2 (&val)[GT_SPG][4]) {
+        if (!(t.flags & 2)) return;
+        // addresses as a wave-uniform base (the first record of the tile's first non-empty span) plus a 32-bit byte offset per
+        // lane: the spans of a tile lie within six grid rows of z, far less than 4 GB apart
+        const long long base_rec = __builtin_amdgcn_readfirstlane(soff[GT_NSPAN + 4]) | ((long long)__builtin_amdgcn_readfirstlane(soff[GT_NSPAN + 5]) << 32);
+        const char *__restrict__ base = reinterpret_cast<const char *>(prec) + base_rec * 64;
+#pragma unroll
+        for (int m = 0; m < GT_SPG; ++m) {
+            const int sp = gq + 16 * m;
+            int32_t sL = 0;
+            long long sG = base_rec;
+            if (sp < GT_NSPAN) {
+                sG = sst[sp * GT_SST];
+                sL = sst[sp * GT_SST + GT_SST - 1] - (int32_t)sG;
+            }
+            const uint32_t o = (uint32_t)((sG - base_rec) * 64) + (uint32_t)(part * 16);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int r = rsub + 4 * st;
+                val[m][st] = make_double2(0.0, 0.0);
+                if (wanted && r < sL) val[m][st] = *reinterpret_cast<const double2 *>(base + (o + (uint32_t)(r * 64)));
+            }
+        }
+    };
+    // stage 3b (the previous tile's walk is over): the cells' lists and the records into LDS -- or, unstaged, the run table
+    auto write_stage = [&](GtTile &t, const double2 (&val)[GT_SPG][4]) {
+        const bool live = (t.flags & 1) != 0;
+        if (t.flags & 2) {
+            ++n_staged;
+            uint16_t *il = reinterpret_cast<uint16_t *>(lds + L::idx) + lane;
+            int pos = t.pos0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { // wave q lists the runs 4 q .. 4 q + 3 of every cell
+                const int r = 4 * wave + q;
+                const int span = (2 * iz + d_gt_zoff(r)) * GT_HR + 2 * iy + d_gt_yoff(r);
+                const int32_t a = sst[span * GT_SST + 2 * ix];
+                const int32_t len = live ? sst[span * GT_SST + 2 * ix + 4] - a : 0;
+                const int32_t first = soff[span] + a - sst[span * GT_SST];
+                for (int32_t e = 0; e < len; ++e) il[(pos + e) * GT_CELLS] = (uint16_t)(first + e);
+                pos += len;
+            }
+#pragma unroll
+            for (int m = 0; m < GT_SPG; ++m) {
+                const int sp = gq + 16 * m;
+                int32_t sL = 0, sG = 0, sO = 0;
+                if (sp < GT_NSPAN) {
+                    sG = sst[sp * GT_SST];
+                    sL = sst[sp * GT_SST + GT_SST - 1] - sG;
+                    sO = soff[sp];
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int r = rsub + 4 * st;
+                    if (wanted && r < sL) d_gt_store<P2G>(rec, mass, sO + r, part, val[m][st]);
+                }
+                // a span longer than the 16 records of the four steps: the rest one by one
+                for (int r = 16 + rsub; wanted && r < sL; r += 4) d_gt_store<P2G>(rec, mass, sO + r, part, src[(long long)(sG + r) * 4 + part]);
+            }
+        } else {
+            ++n_unstaged;
+            // the non-empty runs as (first, end) in global record numbers; every wave writes the same table
+            int2 *runs = reinterpret_cast<int2 *>(lds + L::rec) + lane;
+            int nr = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int span = (2 * iz + d_gt_zoff(r)) * GT_HR + 2 * iy + d_gt_yoff(r);
+                const int32_t a = sst[span * GT_SST + 2 * ix], b = sst[span * GT_SST + 2 * ix + 4];
+                if (live && a < b) { runs[nr * GT_CELLS] = make_int2(a, b); ++nr; }
+            }
+            t.count = nr;
+        }
+    };
+    auto walk = [&](const GtTile &t) {
+        if (!walker) return;
+        const int tix = t.id % tiles_x, tq = t.id / tiles_x;
+        const int i = tix * GT_T + ix, j = (tq % tiles_y) * GT_T + iy, k = (tq / tiles_y) * GT_T + iz;
+        const bool live = (t.flags & 1) != 0, staged = (t.flags & 2) != 0;
+        const long long c = live ? d_lid(g, i, j, k) : 0;
+        if (P2G && role < 3) {
+            // P2G is a template constant: the density-only kernel has no velocity arrays and does not instantiate these
+            if (role == 0) d_gt_role<0, true>(lds, prec, staged, g, lane, t.count, live, i, j, k, c, t.fw, u, active, da);
+            else if (role == 1) d_gt_role<1, true>(lds, prec, staged, g, lane, t.count, live, i, j, k, c, t.fw, v, active, da);
+            else d_gt_role<2, true>(lds, prec, staged, g, lane, t.count, live, i, j, k, c, t.fw, w, active, da);
+        } else {
+            d_gt_role<3, P2G>(lds, prec, staged, g, lane, t.count, live, i, j, k, c, t.fw, nullptr, active, da);
+        }
+    };
+
+    GtPre pre;
+    GtTile cur, nxt;
+    double2 val[GT_SPG][4];
+    issue_pre(id0, pre);
+    write_sst(pre);
+    __syncthreads();
+    setup(id0, pre, cur);
+    issue_stage(cur, val);
+    if (id1 >= 0) issue_pre(id1, pre);
+    for (;;) {
+        __syncthreads(); // the walk of the previous tile is over: its records may go
+        write_stage(cur, val);
+        __syncthreads(); // nobody reads the span boundaries of this tile any more
+        if (id1 >= 0) write_sst(pre);
+        __syncthreads();
+        if (id1 >= 0) {
+            setup(id1, pre, nxt);
+            issue_stage(nxt, val);
+        }
+        if (id2 >= 0) issue_pre(id2, pre);
+        walk(cur);
+        if (id1 < 0) break;
+        cur = nxt;
+        id1 = id2;
+        id2 = tt < t_hi ? tile_list[tt] : -1;
+        tt += per_xcd;
+    }
+    if (tid == 0) {
+        if (n_staged) atomicAdd(stats, n_staged);
+        if (n_unstaged) atomicAdd(stats + 1, n_unstaged);
+    }
+}
+
 // cells of a y-column per thread in the gathers: FLIP_GATHER_COLUMN=1|2 (tuning aid)
 static int gather_column() {
     static const int v = [] { const char *e = getenv("FLIP_GATHER_COLUMN"); const int q = e ? atoi(e) : 2; return q == 1 ? 1 : 2; }();
     return v;
 }
+// Which form of the gather a context uses: flip_set_gather_mode; FLIP_GATHER_TILE=1 makes the LDS-staged form the default
+// of new contexts (tuning aid).
+int flip_default_gather_mode() {
+    static const int v = [] { const char *e = getenv("FLIP_GATHER_TILE"); return (e && atoi(e) == 1) ? 1 : 0; }();
+    return v;
+}
+extern "C" int flip_set_gather_mode(flip_ctx *ctx, int mode) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(mode == 0 || mode == 1, "flip_set_gather_mode: 0 (per-lane walk of global memory) or 1 (LDS-staged tiles)");
+    ctx->gather_mode = mode;
+    return 0;
+}
+template <bool P2G>
+static hipError_t launch_gather_tile(flip_ctx *ctx, const DensityArgs &da, double *u, double *v, double *w, uint8_t *act) {
+    static bool attr_set[64] = {};
+    hipError_t e = hipSuccess;
+    if (!attr_set[ctx->device & 63]) { // more than 64 KB of dynamic LDS has to be asked for, once per device
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gather_tile<P2G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)GatherTileLds<P2G>::total);
+        if (e != hipSuccess) return e;
+        attr_set[ctx->device & 63] = true;
+    }
+    const int tx = (ctx->g.nx + GT_T - 1) / GT_T, ty = (ctx->g.ny + GT_T - 1) / GT_T;
+    // as many workgroups as fit on the device at once (LDS: two per CU with the velocities staged, three without)
+    const int grid = ((ctx->n_cu * (P2G ? 2 : 3) + 7) / 8) * 8;
+    k_gather_tile<P2G><<<grid, 256, GatherTileLds<P2G>::total, ctx->stream>>>(
+        flip_dims(ctx), tx, ty, ctx->tile_list, ctx->tile_scan + ctx->n_tiles, ctx->sub_start, ctx->band,
+        reinterpret_cast<const double *>(ctx->prec), u, v, w, act, da, ctx->gather_stats);
+    return hipGetLastError();
+}
 template <bool P2G>
 static void launch_gather(flip_ctx *ctx, const DensityArgs &da) {
     double *u = P2G ? ctx->vel[1][0] : nullptr, *v = P2G ? ctx->vel[1][1] : nullptr, *w = P2G ? ctx->vel[1][2] : nullptr;
     uint8_t *act = P2G ? ctx->active : nullptr;
+    if (ctx->gather_mode == 1) {
+        if (launch_gather_tile<P2G>(ctx, da, u, v, w, act) == hipSuccess) return;
+        // fall through to the other form; the caller's launch check reports a failure of that one
+    }
     if (gather_column() == 2) {
         const int nyb = (ctx->g.ny + 1) / 2;
         k_gather<P2G, 2><<<flip_grid_blocks((long long)ctx->g.nx * nyb * ctx->g.nz), FLIP_BLOCK, 0, ctx->stream>>>(
@@ -654,6 +1113,16 @@ extern "C" int flip_p2g(flip_ctx *ctx) {
     FLIP_LAUNCH_CHECK();
     ctx->density_valid = true;
     for (int a = 0; a < 3; ++a) std::swap(ctx->vel[0][a], ctx->vel[1][a]);
+    return 0;
+}
+
+extern "C" int flip_gather_stats(flip_ctx *ctx, int64_t out[2]) {
+    FLIP_REQUIRE(ctx && out, "flip_gather_stats: null argument");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    int32_t h[2] = { 0, 0 };
+    FLIP_CHECK(hipMemcpyAsync(h, ctx->gather_stats, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FLIP_CHECK(hipStreamSynchronize(ctx->stream));
+    out[0] = h[0]; out[1] = h[1];
     return 0;
 }
 

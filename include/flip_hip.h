@@ -148,6 +148,14 @@ int64_t flip_field_bytes(const flip_ctx *ctx, int field);
  * Result in velFront; FLIP_F_ACTIVE = particle cells dilated 2.  The same walk over the particles also
  * leaves FLIP_F_DENSITY up to date for the current level set (see flip_density). */
 int flip_p2g(flip_ctx *ctx);
+/* Diagnostic of the LDS-staged gather behind flip_p2g / flip_density (no counterpart in the reference): tiles of
+ * 4 x 4 x 4 cells processed since the context was created, out[0] with their particle records staged in LDS, out[1]
+ * walked from global memory because the tile's support held more records than the staging area (crowded cells). */
+int flip_gather_stats(flip_ctx *ctx, int64_t out[2]);
+/* Selects the form of the gather behind flip_p2g / flip_density (no counterpart in the reference; both forms give
+ * the same bits).  0 (default): every lane walks its cells' particle records in global memory.  1: LDS-staged -- a
+ * workgroup copies the records around a tile of 4 x 4 x 4 cells into LDS once and the cells walk them there. */
+int flip_set_gather_mode(flip_ctx *ctx, int mode);
 /* FluidSimulator::transfer_from_grid_to_particles (src/FluidSimulator.cpp:120-135). */
 int flip_g2p(flip_ctx *ctx, float flip_pic_ratio);
 /* FluidSimulator::apply_particle_displacements (src/FluidSimulator.cpp:137-151). */

@@ -606,6 +606,42 @@ def test_p2g_on_a_wide_box_with_a_crowded_line_is_bit_exact():
         assert np.array_equal(ctx.download("density"), dens)
 
 
+def test_lds_staged_gather_gives_the_same_bits():
+    """The LDS-staged form of the gather (flip_set_gather_mode 1) on the wide box with the crowded line: P2G, activity and
+    density (fused and stand-alone) equal the oracle's bit for bit, with tiles both staged in LDS and -- around the
+    crowded cells -- walked from global memory."""
+    sc = scenes.dam_break(112, ppc=3, seed=4)
+    rng = np.random.default_rng(17)
+    lo = np.array(sc.origin) + np.array(sc.dims) // 2
+    extra = np.concatenate([lo + np.array([dxc, 0, 0]) + rng.uniform(-0.49, 0.49, (90, 3)) for dxc in range(-12, 12)])
+    sc.pos = np.concatenate([sc.pos, extra])
+    sc.vel = rng.normal(0.0, 0.4, sc.pos.shape)
+    sc.mass = np.concatenate([sc.mass, np.full(extra.shape[0], sc.mass[0], np.float32)])
+    sc.mass = (sc.mass * rng.uniform(0.5, 1.5, sc.mass.shape)).astype(np.float32)
+    o = Oracle(sc.desc())
+    _, cell_start, perm, _ = o.bin_particles(sc.pos)
+    pm2 = o.particle_mask(cell_start, 2)
+    want = o.p2g(sc.pos, sc.vel, cell_start, perm, pm2)
+    dens, _ = o.density(sc.pos, sc.mass, cell_start, perm, pm2, sc.phi_fluid)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.set_gather_mode(1)
+        ctx.upload_scene(sc)
+        ctx.bin_particles()
+        before = ctx.gather_stats()
+        ctx.p2g()
+        after = ctx.gather_stats()
+        assert after["staged_tiles"] > before["staged_tiles"] and after["unstaged_tiles"] > before["unstaged_tiles"]
+        for name, ref in zip(("vel_u", "vel_v", "vel_w"), want):
+            assert np.array_equal(ctx.download(name), ref), name
+        assert np.array_equal(ctx.download("active").astype(bool), pm2.astype(bool))
+        assert np.array_equal(ctx.download("density"), dens)
+        ctx.upload("phi_fluid", sc.phi_fluid)      # marks the fused density stale: the density-only launch runs
+        ctx.upload("density", np.zeros_like(dens))
+        ctx.density()
+        assert np.array_equal(ctx.download("density"), dens)
+        assert ctx.gather_stats()["staged_tiles"] > after["staged_tiles"]
+
+
 def test_full_domain_dam_break_properties():
     """The container of the 512^3 configuration (walls at 1 and n-2 on every axis) at reduced size: binning sorted and
     complete, both solves converged to the reference tolerance, particles stay inside the container over several whole
