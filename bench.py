@@ -6,15 +6,19 @@ One "step" is one pass of the loop body of FluidSimulator::advance_flip_pic (src
 the fluid source: binning, fluid level set from the particles, P2G + density, extrapolation, constrain_velocity,
 forces, labels, face fractions, divergence solve + projection, density solve + projection, extrapolation,
 constrain_velocity, G2P, RK3 advection + push-out, displacements -- over the synthetic side-drop dam break at 256^3
-nominal resolution with 8 particles per cell (--n/--ppc select another size for quick runs).  Inputs are generated on
-the host from a fixed seed and uploaded before the timed region.  Rank 0 prints ONE JSON line.  `hot_path_only` in that
+nominal resolution with 8 particles per cell (--n/--ppc select another size for quick runs), substep size 0.001 s: the
+reference limits a substep by compute_cfl (src/FluidSimulator.cpp:448-458, one cell per substep); at 256^3 the falling
+column reaches 1 m/s = 0.26 cells per 0.001 s within the run, while the 0.005 s of earlier rounds exceeded one cell after a
+dozen steps and let the particles clump (thousands per cell), which is not a state the reference's loop produces.  Inputs
+are generated on the host from a fixed seed and uploaded before the timed region.  Rank 0 prints ONE JSON line.  `hot_path_only` in that
 line is the same run without the level-set rebuild, constrain_velocity and advection (the stages outside the
 transfer/solve/projection path), timed right after the headline steps.
 
 N = 1: one context; both solves of a step side by side on two streams.
 N > 1: one process per GPU (this script starts them itself when it is not already running under torch.distributed.run),
-z-slab decomposition (fluidsimulation_amd/distributed.py): CG scalars all-reduced and a few planes per slab face
-exchanged every iteration over RCCL, particles near a face exchanged once per step.
+z-slab decomposition driven by libflip_dist.so (include/flip_dist.h): CG scalars all-reduced and a few planes per slab
+face exchanged every iteration by RCCL calls enqueued on the context's stream, particles near a face exchanged once per
+step (--python-comm: the same loop driven from Python over torch.distributed).
   --scaling strong (default): the one 256^3 box cut into N slabs; `value` = substeps of that box per second.
   --scaling weak: a container N times as long along z, one 256^3-sized slab per rank; `value` = N x substeps/s.
   --full-domain: the container spans the whole nominal grid (with --n 512 --ppc 16: the ~1e9-particle dam break).
@@ -61,7 +65,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=int(os.environ.get("FLIP_BENCH_N", "256")))
     ap.add_argument("--ppc", type=int, default=8)
-    ap.add_argument("--dt", type=float, default=0.005)
+    ap.add_argument("--dt", type=float, default=0.001)
     ap.add_argument("--tol", type=float, default=1e-15)
     ap.add_argument("--max-iter", type=int, default=20000)
     ap.add_argument("--precond", default=os.environ.get("FLIP_BENCH_PRECOND", "mg"), choices=["jacobi", "mg"])
@@ -74,7 +78,10 @@ def parse():
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("FLIP_BENCH_OVERLAP", "-1")),
                     help="N > 1: planes of either neighbour's slab the local preconditioner also covers (additive Schwarz); "
                          "0 = disjoint blocks, default 4")
-    ap.add_argument("--split-phase", action="store_true", help="N = 1: drive the solver through the split-phase entry points")
+    ap.add_argument("--split-phase", action="store_true",
+                    help="N = 1: the slab path (split-phase solver, a one-rank RCCL communicator) through libflip_dist.so")
+    ap.add_argument("--python-comm", action="store_true",
+                    help="slab runs: drive the communication from Python (torch.distributed) instead of libflip_dist.so")
     ap.add_argument("--hot-path-only", action="store_true",
                     help="time only the transfer/solve/projection path (no level-set rebuild, constrain_velocity, advection)")
     ap.add_argument("--full-substep", action="store_true", help="accepted for compatibility: the whole substep is the default now")
@@ -245,7 +252,8 @@ def stored_traffic(args):
         return {}, None
     with open(path) as f:
         d = json.load(f)
-    if d.get("source_id") != kernel_source_id() or d.get("n") != args.n or d.get("ppc") != args.ppc or d.get("hot_path_only", False) != args.hot_path_only:
+    if (d.get("source_id") != kernel_source_id() or d.get("n") != args.n or d.get("ppc") != args.ppc
+            or d.get("hot_path_only", False) != args.hot_path_only or d.get("dt") != args.dt):
         return {}, None
     return d.get("bytes_per_launch", {}), d.get("files")
 
@@ -263,6 +271,13 @@ def time_stage(torch, fn, reps=3):
     return total / reps * 1e-3
 
 
+def stage_entry(seconds, per_step, algorithmic_bytes, what):
+    """A stage of several kernels: reported beside the kernels, never picked as the roofline kernel."""
+    gbs = algorithmic_bytes / seconds / 1e9
+    return {"seconds": seconds, "per_step": per_step, "ms_per_step": seconds * per_step * 1e3, "algorithmic_bytes": algorithmic_bytes,
+            "achieved_GBps": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS, "what": what}
+
+
 def roofline_entry(name, seconds, launches_per_step, algorithmic_bytes, traffic, note=None):
     gbs = algorithmic_bytes / seconds / 1e9
     e = {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -277,6 +292,11 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
+    # stdout carries the one JSON line and nothing else: libraries that greet on stdout (RCCL prints its version there
+    # when a communicator is created) are sent to stderr, and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -342,8 +362,17 @@ def main():
     overlap = 0
     if slabs:
         overlap = min(4 if args.overlap < 0 else args.overlap, max(ghost - 1, 0)) if world > 1 else 0
-        step = DistributedSubstep(ctx, layout, Comm(), device=local, tol=args.tol, max_iter=args.max_iter, precond=precond,
-                                  overlap=overlap, **extra)
+        if args.python_comm:
+            step = DistributedSubstep(ctx, layout, Comm(), device=local, tol=args.tol, max_iter=args.max_iter, precond=precond,
+                                      overlap=overlap, **extra)
+        else:
+            from fluidsimulation_amd.dist_native import NativeDistributedSubstep, TorchTransport
+            comm = Comm()
+            # RCCL refuses several ranks on one device: the rehearsal on a one-GPU box goes through the library's transport
+            # callbacks over gloo instead
+            step = NativeDistributedSubstep(ctx, layout, comm, device=local, tol=args.tol, max_iter=args.max_iter, precond=precond,
+                                            overlap=overlap, transport=TorchTransport(comm, local) if rehearse and world > 1 else "rccl",
+                                            force_slab=world == 1, **extra)
     else:
         step = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=precond,
                            concurrent_solves=not args.sequential_solves, **extra)
@@ -399,7 +428,7 @@ def main():
     pcg_gbs = iters * rows * it_bytes / pcg_s / 1e9 if pcg_s > 0 else 0.0
     spmv_s = sum(s["spmv_seconds"] for s in solves)
     spmv_n = sum(s["spmv_launches"] for s in solves)
-    entries = []
+    entries, stages = [], {}
     jacobi_iters = None
     if rank == 0:
         traffic, traffic_files = stored_traffic(args) if world == 1 else ({}, None)
@@ -417,31 +446,37 @@ def main():
                     entries.append(roofline_entry(name, kt[name] * 1e-6, its_per_step, rows * BYTES[name], traffic,
                                                   note="one profiled iteration, device otherwise idle"))
             if kt.get("coarse_levels"):
-                entries.append({"kernel": "coarse_levels", "bound": "latency", "avg_launch_us": kt["coarse_levels"],
-                                "launches_per_step": its_per_step, "ms_per_step": kt["coarse_levels"] * its_per_step * 1e-3,
-                                "note": "all launches of the V-cycle below level 0 of one iteration, run alone; beside the other solve's "
-                                        "level-0 kernels they mostly hide"})
-        # particle-side stages, timed alone on the state the run has reached
+                # 13 launches, not one kernel: a stage.  ~34 B per level-0 row is what the levels below 0 move (1/8 + 1/64 + ...)
+                t_c = kt["coarse_levels"] * 1e-6
+                stages["coarse_levels"] = stage_entry(t_c, its_per_step, rows * 34, "all launches of the V-cycle below level 0 of one "
+                                                      "iteration, run alone (bound by launch and dependent-load latency; beside the other "
+                                                      "solve's level-0 kernels they mostly hide)")
+        # particle-side kernels and stages, timed alone on the state the run has reached
         ctx.bin_particles(want_outside=False)
         if not args.hot_path_only:
             t_ls = time_stage(torch, lambda: ctx.fluid_levelset_from_particles(radius))
-            entries.append(roofline_entry("k_fluid_levelset", t_ls, 1, LEVELSET_BYTES_PER_PARTICLE * n_local + LEVELSET_BYTES_PER_CELL * sc.n_cells,
-                                          traffic, note="whole stage (occupancy dilation + search)"))
+            stages["fluid_levelset"] = stage_entry(t_ls, 1, LEVELSET_BYTES_PER_PARTICLE * n_local + LEVELSET_BYTES_PER_CELL * sc.n_cells,
+                                                   "whole stage: occupancy dilation, shells 0-1 for every cell, compaction, full search of the rest")
         t_p2g = time_stage(torch, ctx.p2g)
         band = int(ctx.download("active").astype(np.int64).sum())
         ctx.update_diff()
         t_g2p = time_stage(torch, lambda: ctx.g2p(0.95))
         entries.append(roofline_entry("k_gather", t_p2g, 1, P2G_BYTES_PER_PARTICLE * n_local + P2G_BYTES_PER_BAND_CELL * band, traffic,
-                                      note="P2G; the same launch also accumulates the density field"))
+                                      note="flip_p2g = this one kernel (k_gather<true, 2>): P2G and, in the same walk, the density field"))
         entries.append(roofline_entry("k_g2p", t_g2p, 1, G2P_BYTES_PER_PARTICLE * n_local + G2P_BYTES_PER_BAND_CELL * band, traffic))
-
-        def rebin():
-            ctx.apply_displacements()     # marks the sort stale (the displacement field is whatever the last step left)
+        # binning as the substep meets it: right after a whole substep (which ends with moved particles, the sort stale)
+        t_bin = 0.0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            step.step(args.dt)
+            barrier()                     # the substep's own work is done before the clock starts
+            e0.record()
             ctx.bin_particles(want_outside=False)
-        t_disp = time_stage(torch, ctx.apply_displacements)
-        t_bin = time_stage(torch, rebin) - t_disp
-        entries.append(roofline_entry("binning", t_bin, 1, SORT_BYTES_PER_PARTICLE * n_local, traffic,
-                                      note="whole stage: cell ids, scan, slots, per-cell sort, reorder, half-cell ordered copy, bands"))
+            e1.record()
+            e1.synchronize()
+            t_bin += e0.elapsed_time(e1) * 1e-3 / 3
+        stages["binning"] = stage_entry(t_bin, 1, SORT_BYTES_PER_PARTICLE * n_local, "whole stage after a real substep: cell ids, scan, slots, "
+                                        "per-row reorder (stable order + half-cell ordered copy), bands, gather tile list")
         if world == 1 and not args.no_cpu_baseline and not slabs:
             # iteration counts of the reference's own solver (Jacobi CG) on this scene, for the CPU extrapolation
             probe = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=PRECOND_JACOBI).step(args.dt)
@@ -471,7 +506,8 @@ def main():
         roofline = dict(dominant) if dominant else {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS,
                                                      "unit": "GB/s", "frac": None, "traffic": None}
         roofline["traffic_source"] = traffic_files if roofline.get("traffic") else None
-        roofline["selection"] = "the kernel with the largest time per step among those timed on their own (ms_per_step)"
+        roofline["selection"] = ("the kernel (a name rocprofv3's kernel statistics list) with the largest time per step among those timed on "
+                                 "their own; stages of several kernels are under `stages`")
         scaling = "weak" if (weak or (world > 1 and not slabs)) else "strong"
         units = world if scaling == "weak" else 1
         out = {
@@ -495,6 +531,7 @@ def main():
                     "converged": all(s["converged"] == 1 for s in solves)},
             "roofline": roofline,
             "roofline_other_kernels": {e["kernel"]: e for e in entries if not e["dominant"]},
+            "stages": stages,
         }
         if jacobi_iters is not None:
             # the CPU works on the state the device has reached, not on the fluid at rest: from rest the vectors of the
@@ -502,7 +539,8 @@ def main():
             sc.pos, sc.vel = ctx.download_particles()
             sc.phi_fluid = ctx.download("phi_fluid")
             out["cpu_baseline"] = cpu_baseline(sc, args, jacobi_iters)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -56,8 +56,8 @@ PRECOND_JACOBI, PRECOND_MULTIGRID = 0, 1
 
 # every symbol include/flip_hip.h declares
 EXPORTS = [
-    "flip_ctx_create", "flip_ctx_destroy", "flip_last_error", "flip_synchronize", "flip_get_desc",
-    "flip_particles_upload", "flip_particles_download", "flip_particles_count", "flip_bin_particles",
+    "flip_ctx_create", "flip_ctx_destroy", "flip_get_stream", "flip_system_dependent_coupled", "flip_last_error", "flip_synchronize", "flip_get_desc",
+    "flip_particles_upload", "flip_particles_download", "flip_particles_download_mass", "flip_particles_count", "flip_bin_particles",
     "flip_binning_download", "flip_field_upload", "flip_field_download", "flip_field_bytes", "flip_p2g", "flip_gather_stats", "flip_set_gather_mode", "flip_g2p",
     "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_fluid_levelset_from_particles", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
     "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_velocity_max_static", "flip_index_cells", "flip_face_fractions",
@@ -89,8 +89,11 @@ def load_library(path: str = LIB_PATH):
         "flip_last_error": (C.c_char_p, [vp]),
         "flip_synchronize": (C.c_int, [vp]),
         "flip_get_desc": (C.c_int, [vp, P(GridDesc)]),
+        "flip_get_stream": (C.c_int, [vp, P(vp), P(C.c_int)]),
+        "flip_system_dependent_coupled": (C.c_int, [vp, P(i32)]),
         "flip_particles_upload": (C.c_int, [vp, i64, vp, vp, vp]),
         "flip_particles_download": (C.c_int, [vp, vp, vp]),
+        "flip_particles_download_mass": (C.c_int, [vp, vp]),
         "flip_particles_count": (i64, [vp]),
         "flip_bin_particles": (C.c_int, [vp, P(i64)]),
         "flip_binning_download": (C.c_int, [vp, vp, vp, vp]),
@@ -209,6 +212,11 @@ class FlipContext:
         self._check(self.lib.flip_particles_download(self.h, _ptr(pos), _ptr(vel)))
         return pos, vel
 
+    def download_mass(self):
+        m = np.zeros(self.particle_count(), np.float32)
+        self._check(self.lib.flip_particles_download_mass(self.h, _ptr(m)))
+        return m
+
     def bin_particles(self, want_outside: bool = True) -> int:
         out = C.c_int64(0)
         self._check(self.lib.flip_bin_particles(self.h, C.byref(out) if want_outside else None))
@@ -243,6 +251,11 @@ class FlipContext:
         out = (C.c_int64 * 2)()
         self._check(self.lib.flip_gather_stats(self.h, out))
         return {"staged_tiles": int(out[0]), "unstaged_tiles": int(out[1])}
+
+    def system_dependent_coupled(self) -> int:
+        n = C.c_int32(0)
+        self._check(self.lib.flip_system_dependent_coupled(self.h, C.byref(n)))
+        return int(n.value)
 
     def set_gather_mode(self, mode: int):
         self._check(self.lib.flip_set_gather_mode(self.h, int(mode)))

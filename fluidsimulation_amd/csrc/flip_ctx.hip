@@ -251,6 +251,12 @@ extern "C" int flip_synchronize(flip_ctx *ctx) {
     FLIP_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
+extern "C" int flip_get_stream(const flip_ctx *ctx, void **stream, int *device) {
+    if (!ctx || !stream) return 1;
+    *stream = (void *)ctx->stream;
+    if (device) *device = ctx->device;
+    return 0;
+}
 extern "C" int flip_get_desc(const flip_ctx *ctx, flip_grid_desc *out) {
     if (!ctx || !out) return 1;
     *out = ctx->g;
@@ -413,6 +419,23 @@ extern "C" int flip_particles_download(flip_ctx *ctx, double *pos, double *vel) 
         FLIP_LAUNCH_CHECK();
         FLIP_CHECK(hipMemcpyAsync(vel, ctx->stage + 3 * ctx->cap, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
     }
+    FLIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+__global__ void k_pack_mass(long long n, const float *__restrict__ m, const int32_t *__restrict__ pid, float *__restrict__ out) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) out[pid[s]] = m[s];
+}
+extern "C" int flip_particles_download_mass(flip_ctx *ctx, float *mass) {
+    FLIP_REQUIRE(ctx && mass, "flip_particles_download_mass: null argument");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    if (n == 0) return 0;
+    float *tmp = reinterpret_cast<float *>(ctx->stage);
+    k_pack_mass<<<flip_grid_blocks(n), FLIP_BLOCK, 0, ctx->stream>>>(n, ctx->mass[ctx->cur], ctx->pid[ctx->cur], tmp);
+    FLIP_LAUNCH_CHECK();
+    FLIP_CHECK(hipMemcpyAsync(mass, tmp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     FLIP_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -163,6 +163,7 @@ struct flip_ctx {
     bool drop_null_rows = true;     // rhs of all-zero rows forced to 0
     bool eliminate_dep = true;      // rows of cells with phi_fluid >= 0 are eliminated from the CG system
     bool sys_eliminated = false;    // the assembled system carries FLIP_FLAG_DEP rows
+    int32_t sys_dep_coupled = 0;    // dependent rows with a rigid-body entry found by the last assembly (they rule the elimination out)
     float *term[3] = {};            // (1 - W) * scale at the low x/y/z face of every cell
     uint8_t *flags = nullptr;
     double *diag = nullptr, *invdiag = nullptr, *rhs = nullptr;

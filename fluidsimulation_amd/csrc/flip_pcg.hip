@@ -321,6 +321,7 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     A.drop_null = ctx->drop_null_rows ? 1 : 0;
     A.eliminate = ctx->eliminate_dep ? 1 : 0;
     A.counters = ctx->d_counts;
+    ctx->sys_dep_coupled = 0;
     A.ou = ctx->owgt[0]; A.ov = ctx->owgt[1]; A.ow = ctx->owgt[2];
     for (int a = 0; a < 3; ++a) A.com[a] = ctx->obj_com[a];
     for (int a = 0; a < 6; ++a) { A.minv[a] = ctx->obj_minv[a]; A.vel[a] = ctx->obj_vel[a]; A.J[a] = ctx->J[a]; }
@@ -334,7 +335,10 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
         int32_t cnt[2] = { 0, 0 };
         FLIP_CHECK(hipMemcpyAsync(cnt, ctx->d_counts + 4, 8, hipMemcpyDeviceToHost, st));
         FLIP_CHECK(hipStreamSynchronize(st));
-        if (cnt[1] > 0) {
+        ctx->sys_dep_coupled = cnt[1];
+        // A slab context keeps the eliminated system: whether to drop the elimination is a property of all slabs together,
+        // and the slab solver has no other form; the caller asks flip_system_dependent_coupled on every rank and agrees.
+        if (cnt[1] > 0 && !ctx->slab_on) {
             A.eliminate = 0;
             FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 4, 0, 8, st));
             k_build_system<<<ctx->n_chunks, FLIP_BLOCK, 0, st>>>(A);
@@ -384,6 +388,13 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     ctx->sys_s2 = A.s2;
     ctx->sys_coupled = A.coupled != 0;
     ctx->sys_eliminated = A.eliminate != 0;
+    return 0;
+}
+
+extern "C" int flip_system_dependent_coupled(flip_ctx *ctx, int32_t *count) {
+    FLIP_REQUIRE(ctx && count, "flip_system_dependent_coupled: null argument");
+    FLIP_REQUIRE(ctx->sys_kind >= 0, "flip_system_dependent_coupled: no system assembled");
+    *count = ctx->sys_dep_coupled;
     return 0;
 }
 

@@ -1,0 +1,199 @@
+"""ctypes binding of libflip_dist.so (include/flip_dist.h): the z-slab driver in C over RCCL.
+
+`NativeDistributedSubstep` has the interface of distributed.DistributedSubstep (step(dt) -> info) and runs the whole
+substep, communication included, inside the library: every collective is enqueued on the context's stream between the
+kernels.  The transport is RCCL (the unique id travels over torch.distributed, which also started the ranks) or, for
+ranks that share one GPU and for the CPU-side tests, torch.distributed/gloo through the library's transport callbacks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .binding import FlipError, PcgInfo, PRECOND_MULTIGRID, load_library
+
+DIST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libflip_dist.so")
+FORCE_SLAB = 1
+SUM, MAX = 0, 1
+
+# every symbol include/flip_dist.h declares
+DIST_EXPORTS = ["flip_dist_unique_id", "flip_dist_create", "flip_dist_create_with_transport", "flip_dist_destroy", "flip_dist_last_error",
+                "flip_dist_solve", "flip_dist_exchange_particles", "flip_dist_last_exchange", "flip_dist_all_reduce", "flip_dist_substep"]
+
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                          C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_reduce", ALL_REDUCE_FN), ("exchange", EXCHANGE_FN)]
+
+
+class StepOptions(C.Structure):
+    _fields_ = [("flip_pic_ratio", C.c_float), ("tol", C.c_double), ("max_iter", C.c_int32), ("precond", C.c_int32),
+                ("density_projection", C.c_int32), ("constrain", C.c_int32), ("advect", C.c_int32), ("rigid_body", C.c_int32),
+                ("levelset_radius", C.c_float)]
+
+
+_dist_lib = None
+
+
+def load_dist_library(path: str = DIST_LIB_PATH):
+    """Load libflip_dist.so (after libflip_hip.so, which it links against).  Raises FlipError when it has not been built."""
+    global _dist_lib
+    if _dist_lib is not None:
+        return _dist_lib
+    load_library()
+    if not os.path.exists(path):
+        raise FlipError(f"{path} not found: build it with `make -C fluidsimulation_amd/csrc`")
+    lib = C.CDLL(path)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    P = C.POINTER
+    sig = {
+        "flip_dist_unique_id": (C.c_int, [vp]),
+        "flip_dist_create": (C.c_int, [vp, C.c_int, C.c_int, vp, P(i32), i32, i32, i64, C.c_int, P(vp)]),
+        "flip_dist_create_with_transport": (C.c_int, [vp, C.c_int, C.c_int, P(Transport), P(i32), i32, i32, i64, C.c_int, P(vp)]),
+        "flip_dist_destroy": (None, [vp]),
+        "flip_dist_last_error": (C.c_char_p, [vp]),
+        "flip_dist_solve": (C.c_int, [vp, C.c_int, C.c_float, C.c_double, i32, C.c_int, P(PcgInfo)]),
+        "flip_dist_exchange_particles": (C.c_int, [vp, P(i64), P(i64)]),
+        "flip_dist_last_exchange": (C.c_int, [vp, P(i64), P(i64)]),
+        "flip_dist_all_reduce": (C.c_int, [vp, P(C.c_double), i32, C.c_int]),
+        "flip_dist_substep": (C.c_int, [vp, C.c_float, P(StepOptions), P(PcgInfo)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _dist_lib = lib
+    return lib
+
+
+class TorchTransport:
+    """The library's transport callbacks over torch.distributed (distributed.Comm): with gloo the buffers are staged
+    through the host, so ranks may share one GPU.  The device is synchronised around every operation, which orders it
+    against the library's stream."""
+
+    def __init__(self, comm, device: int):
+        import torch
+        from .distributed import _DeviceArray
+        self.comm, self.device, self.torch = comm, device, torch
+        self._DeviceArray = _DeviceArray
+        self.error = None
+        self._ar = ALL_REDUCE_FN(self._all_reduce)
+        self._ex = EXCHANGE_FN(self._exchange)
+        self.struct = Transport(None, self._ar, self._ex)
+
+    def _tensor(self, ptr, n, typestr):
+        if not ptr or n <= 0:
+            return None
+        arr = self._DeviceArray(int(ptr), int(n))
+        arr.__cuda_array_interface__["typestr"] = typestr
+        return self.torch.as_tensor(arr, device=self.torch.device("cuda", self.device))
+
+    def _all_reduce(self, user, buf, count, op, stream):
+        try:
+            self.torch.cuda.synchronize(self.device)
+            t = self._tensor(buf, count, "<f8")
+            (self.comm.all_reduce_max if op == MAX else self.comm.all_reduce_sum)(t)
+            self.torch.cuda.synchronize(self.device)
+            return 0
+        except BaseException as e:  # an exception cannot cross the C frames
+            self.error = e
+            return 1
+
+    def _exchange(self, user, send_lo, n_send_lo, recv_lo, n_recv_lo, send_hi, n_send_hi, recv_hi, n_recv_hi, stream):
+        try:
+            self.torch.cuda.synchronize(self.device)
+            self.comm.exchange(self._tensor(send_lo, n_send_lo, "|u1"), self._tensor(recv_lo, n_recv_lo, "|u1"),
+                               self._tensor(send_hi, n_send_hi, "|u1"), self._tensor(recv_hi, n_recv_hi, "|u1"))
+            self.torch.cuda.synchronize(self.device)
+            return 0
+        except BaseException as e:
+            self.error = e
+            return 1
+
+
+class NativeDistributedSubstep:
+    """distributed.DistributedSubstep with the orchestration and the communication inside libflip_dist.so.
+
+    transport: "rccl" (default: a communicator of its own; the unique id is broadcast over the torch.distributed group
+    that is already up) or a TorchTransport."""
+
+    def __init__(self, ctx, layout, comm, device: int = 0, flip_pic_ratio: float = 0.95, tol: float = 1e-15, max_iter: int = 20000,
+                 precond: int = PRECOND_MULTIGRID, density_projection: bool = True, overlap: int = 0, constrain: bool = False,
+                 advect: bool = False, levelset_radius: float | None = None, rigid_body: bool = False, transport="rccl",
+                 force_slab: bool = False, particle_capacity: int | None = None):
+        self.lib = load_dist_library()
+        self.ctx, self.layout, self.comm = ctx, layout, comm
+        rank, world = comm.rank, comm.world
+        assert layout.world == world
+        starts = (C.c_int32 * (world + 1))(*layout.starts)
+        cap = particle_capacity if particle_capacity is not None else ctx.particle_count() * 5 // 4 + 4096
+        h = C.c_void_p()
+        flags = FORCE_SLAB if force_slab else 0
+        self.transport = transport
+        if transport == "rccl":
+            uid = (C.c_uint8 * 128)()
+            if world > 1:
+                import torch
+                import torch.distributed as dist
+                if rank == 0 and self.lib.flip_dist_unique_id(uid) != 0:
+                    raise FlipError(self.lib.flip_dist_last_error(None).decode())
+                t = torch.tensor(list(uid), dtype=torch.uint8)
+                if comm.backend == "nccl":
+                    t = t.cuda(device)
+                dist.broadcast(t, 0, group=comm.group)
+                uid = (C.c_uint8 * 128)(*t.cpu().tolist())
+            elif self.lib.flip_dist_unique_id(uid) != 0:
+                raise FlipError(self.lib.flip_dist_last_error(None).decode())
+            rc = self.lib.flip_dist_create(ctx.h, rank, world, uid, starts, layout.ghost, overlap if world > 1 else 0, cap, flags, C.byref(h))
+        else:
+            rc = self.lib.flip_dist_create_with_transport(ctx.h, rank, world, C.byref(transport.struct), starts, layout.ghost,
+                                                          overlap if world > 1 else 0, cap, flags, C.byref(h))
+        if rc != 0:
+            raise FlipError(self.lib.flip_dist_last_error(None).decode())
+        self.h = h
+        self.opt = StepOptions(flip_pic_ratio, tol, max_iter, precond, int(density_projection), int(constrain), int(advect), int(rigid_body),
+                               float(levelset_radius) if levelset_radius is not None else 0.0)
+        self.density_projection = density_projection
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.flip_dist_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            err = getattr(self.transport, "error", None)
+            if err is not None:
+                raise err
+            raise FlipError(self.lib.flip_dist_last_error(self.h).decode())
+
+    def all_reduce(self, values, op=SUM):
+        a = np.ascontiguousarray(values, np.float64)
+        self._check(self.lib.flip_dist_all_reduce(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size, op))
+        return a
+
+    def solve(self, kind: int, dt: float) -> dict:
+        info = PcgInfo()
+        self._check(self.lib.flip_dist_solve(self.h, kind, dt, self.opt.tol, self.opt.max_iter, self.opt.precond, C.byref(info)))
+        return info.as_dict()
+
+    def step(self, dt: float) -> dict:
+        infos = (PcgInfo * 2)()
+        self._check(self.lib.flip_dist_substep(self.h, dt, C.byref(self.opt), infos))
+        out = {"divergence": infos[0].as_dict(), "density": infos[1].as_dict() if self.density_projection else None}
+        if self.comm.world > 1:
+            sent, recv = (C.c_int64 * 2)(), (C.c_int64 * 2)()
+            self.lib.flip_dist_last_exchange(self.h, sent, recv)
+            out["exchange"] = {"sent": (int(sent[0]), int(sent[1])), "received": (int(recv[0]), int(recv[1]))}
+        return out

@@ -350,6 +350,18 @@ class DistributedSubstep:
 
     def solve(self, kind: int, dt: float) -> dict:
         self.ctx.build_system(kind, dt)
+        if self.rigid_body and self.comm.world > 1:
+            # The slab solver works on the eliminated system.  A rigid-body row that is also a dependent row (a free-surface
+            # cell next to the body) rules that out, and whether one exists is a property of all slabs together: agree before
+            # the first collective of the solve, so that every rank takes the same way out.
+            import torch
+            flag = torch.tensor([float(self.ctx.system_dependent_coupled() > 0)], dtype=torch.float64)
+            if self.comm.backend == "nccl":
+                flag = flag.cuda()
+            self.comm.all_reduce_max(flag)
+            if float(flag.cpu()[0]) > 0:
+                raise RuntimeError("the rigid body touches dependent rows (cells with phi_fluid >= 0 that carry a pressure row) on some "
+                                   "rank; the slab solver needs the eliminated system, which such rows rule out")
         return slab_pcg_solve(self.solver, self.comm, self.tol, self.max_iter, self.precond)
 
     def step(self, dt: float) -> dict:

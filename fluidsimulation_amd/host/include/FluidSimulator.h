@@ -5,6 +5,8 @@
 #include "FluidDomain.h"
 #include "flipvdb.h"
 
+#include "../../../include/flip_dist.h"
+
 struct FlipSolveReport {
     int converged = 0, iterations = 0, rows = 0;
     double rel_residual = 0.0, seconds = 0.0;
@@ -38,6 +40,14 @@ public:
     int substeps_taken = 0;
     FlipSolveReport last_divergence_solve, last_density_solve;
 
+    // ---- several GPUs: one process per GPU, each with the FluidDomain of its z-slab (no counterpart in the reference).
+    // attach() hands over the slab handle of include/flip_dist.h built on this domain's context; from then on the two
+    // solves run over all slabs (RCCL all-reduces and plane exchanges on the context's stream), compute_cfl takes the
+    // maximum over all ranks, the rigid body's velocity update sums J p over all slabs, and every substep ends with the
+    // exchange of the particles near the slab faces.  nullptr (the default): one context, as before.
+    void attach(flip_dist *slab) { _dist = slab; }
+    flip_dist *attached() const { return _dist; }
+
 private:
     float compute_cfl(FluidDomain &domain);
     void transfer_from_particles_to_grid(FluidDomain &domain);
@@ -54,5 +64,7 @@ private:
     void transfer_from_grid_to_particles(FluidDomain &domain, float flip_pic_ratio);
     void apply_particle_displacements(FluidDomain &domain);
     const flipvdb::CoordBBox _bbox;
+    flip_dist *_dist = nullptr;
+    void check_dist(int rc, const char *what) const;
     bool _density_already_solved = false;  // this substep's density system was solved together with the divergence one
 };

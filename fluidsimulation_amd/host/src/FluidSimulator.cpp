@@ -3,6 +3,8 @@
 
 #include <chrono>
 #include <cstdio>
+#include <stdexcept>
+#include <string>
 
 using namespace flipvdb;
 using namespace std::chrono;
@@ -19,6 +21,10 @@ double hat(double x) {        // headers/util.h:470-478
 FluidSimulator::FluidSimulator(): _bbox() {}
 FluidSimulator::FluidSimulator(CoordBBox bbox): _bbox(bbox) {}
 FluidSimulator::~FluidSimulator() {}
+
+void FluidSimulator::check_dist(int rc, const char *what) const {
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + flip_dist_last_error(_dist));
+}
 
 // src/FluidSimulator.cpp:1347-1371
 double FluidSimulator::calculate_kernel_function(Vec3d vec) { return calculate_kernel_function(vec[0], vec[1], vec[2]); }
@@ -70,6 +76,7 @@ void FluidSimulator::advance_flip_pic(FluidDomain &domain, float t_frame, float 
         transfer_from_grid_to_particles(domain, flip_pic_ratio);
         if (advect) domain.advectParticles(timestep);
         if (density_constraint) apply_particle_displacements(domain);
+        if (_dist) check_dist(flip_dist_exchange_particles(_dist, nullptr, nullptr), "flip_dist_exchange_particles");
         for (auto solidObj : domain.solidObjs()) { solidObj->update_positions_orientations(timestep); }
         dev.check(flip_synchronize(dev.ctx()), "flip_synchronize");
         auto t2 = high_resolution_clock::now();
@@ -91,6 +98,11 @@ float FluidSimulator::compute_cfl(FluidDomain &domain) {
     for (auto solidObject : domain.solidObjs()) {
         const Vec3d a = solidObject->velTranslational();
         for (int c = 0; c < 3; ++c) maxVector[c] = std::max(maxVector[c], std::fabs(a[c]));
+    }
+    if (_dist) { // the substep size is one number for all slabs
+        double m3[3] = { maxVector[0], maxVector[1], maxVector[2] };
+        check_dist(flip_dist_all_reduce(_dist, m3, 3, FLIP_DIST_MAX), "flip_dist_all_reduce");
+        maxVector = Vec3d(m3[0], m3[1], m3[2]);
     }
     return domain.voxelSize() / (std::max(maxVector[0], std::max(maxVector[1], maxVector[2])) + epsilon);
 }
@@ -161,6 +173,20 @@ void FluidSimulator::solve_pressure_divirgence(FluidDomain &domain, float dt) {
     FlipDevice &dev = domain.device();
     flip_pcg_info info;
     _density_already_solved = false;
+    if (_dist) {
+        // over all slabs; flip_project_velocity leaves the body alone on a slab context, its update takes the J p of every slab
+        check_dist(flip_dist_solve(_dist, FLIP_SOLVE_DIVERGENCE, dt, solver_tolerance, solver_max_iterations, preconditioner, &info), "flip_dist_solve");
+        last_divergence_solve = report(info);
+        dev.check(flip_project_velocity(dev.ctx(), dt), "flip_project_velocity");
+        if (!domain.solidObjs().empty()) {
+            double jp[6];
+            dev.check(flip_solid_coupling_partial(dev.ctx(), jp), "flip_solid_coupling_partial");
+            check_dist(flip_dist_all_reduce(_dist, jp, 6, FLIP_DIST_SUM), "flip_dist_all_reduce");
+            dev.check(flip_solid_velocity_apply(dev.ctx(), dt, jp), "flip_solid_velocity_apply");
+        }
+        domain.fetchSolidObjectVelocity();
+        return;
+    }
     if (density_constraint && concurrent_solves) {
         flip_pcg_info info_density;
         dev.check(flip_solve_pair(dev.ctx(), dt, solver_tolerance, solver_max_iterations, preconditioner, &info, &info_density),
@@ -186,6 +212,12 @@ void FluidSimulator::solve_pressure_density(FluidDomain &domain, float dt) {
         return;
     }
     flip_pcg_info info;
+    if (_dist) {
+        check_dist(flip_dist_solve(_dist, FLIP_SOLVE_DENSITY, dt, solver_tolerance, solver_max_iterations, preconditioner, &info), "flip_dist_solve");
+        last_density_solve = report(info);
+        dev.check(flip_project_displacement(dev.ctx(), dt), "flip_project_displacement");
+        return;
+    }
     dev.check(flip_build_system(dev.ctx(), FLIP_SOLVE_DENSITY, dt), "flip_build_system");
     dev.check(flip_pcg_solve(dev.ctx(), solver_tolerance, solver_max_iterations, preconditioner, &info), "flip_pcg_solve");
     last_density_solve = report(info);

@@ -13,7 +13,8 @@ ParticleSet::ParticleSet(Transform::Ptr i2w_transform): _i2w_transform(i2w_trans
 ParticleSet::~ParticleSet() {}
 
 int ParticleSet::size() const {
-    // the count never changes on the device, so the host vector's size is always current
+    // the count changes on the device only through the particle exchange of a slab decomposition (pull() then resizes)
+    if (_host_stale && _device) return (int)flip_particles_count(_device->ctx());
     return (int)_particles.size();
 }
 
@@ -27,9 +28,18 @@ void ParticleSet::attach(std::shared_ptr<FlipDevice> device) {
 
 void ParticleSet::pull() {
     if (!_host_stale || !_device) return;
-    const size_t n = _particles.size();
+    const size_t n = (size_t)flip_particles_count(_device->ctx());
     std::vector<double> pos(3 * n), vel(3 * n);
     _device->check(flip_particles_download(_device->ctx(), pos.data(), vel.data()), "flip_particles_download");
+    if (n != _particles.size()) {
+        // a particle exchange between slabs replaced the set: masses come from the device, the radius is the sources' one
+        // radius for all (src/FluidSource.cpp:67), taken from a particle this set already had
+        const float radius = _particles.empty() ? 0.f : _particles[0].radius();
+        std::vector<float> mass(n);
+        _device->check(flip_particles_download_mass(_device->ctx(), mass.data()), "flip_particles_download_mass");
+        _particles.assign(n, Particle(Vec3d(0, 0, 0), Vec3d(0, 0, 0), radius, 0.f));
+        for (size_t q = 0; q < n; ++q) _particles[q] = Particle(Vec3d(0, 0, 0), Vec3d(0, 0, 0), radius, mass[q]);
+    }
     for (size_t q = 0; q < n; ++q) {
         _particles[q].setPosition(Vec3d(pos[3 * q], pos[3 * q + 1], pos[3 * q + 2]));
         _particles[q].setVelocity(Vec3d(vel[3 * q], vel[3 * q + 1], vel[3 * q + 2]));

@@ -116,6 +116,9 @@ void flip_ctx_destroy(flip_ctx *ctx);
 const char *flip_last_error(const flip_ctx *ctx);
 int flip_synchronize(flip_ctx *ctx);
 int flip_get_desc(const flip_ctx *ctx, flip_grid_desc *out);
+/* The hipStream_t every call on this context enqueues its work on, and the context's device: for callers that order
+ * their own device work (communication, include/flip_dist.h) between the library's kernels. */
+int flip_get_stream(const flip_ctx *ctx, void **stream, int *device);
 
 /* ---- particles: ParticleSet (headers/ParticleSet.h:43-116) --------------------------------- */
 
@@ -123,6 +126,9 @@ int flip_get_desc(const flip_ctx *ctx, flip_grid_desc *out);
 int flip_particles_upload(flip_ctx *ctx, int64_t n, const double *pos, const double *vel, const float *mass);
 /* ParticleSet::operator[] for a whole set, in upload order.  Any pointer may be NULL. */
 int flip_particles_download(flip_ctx *ctx, double *pos, double *vel);
+/* Particle::mass() for a whole set, in the order of flip_particles_download.  After a particle exchange of the slab
+ * decomposition the set is not the uploaded one any more: count, then positions, velocities and masses describe it. */
+int flip_particles_download_mass(flip_ctx *ctx, float *mass);
 int64_t flip_particles_count(const flip_ctx *ctx);
 
 /* Replaces ParticleAtlas::create + createPointMask + dilateActiveValues
@@ -296,6 +302,11 @@ int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1);
  * returns this context's share of J p (rows of its owned planes); the caller sums it over the ranks and passes the total
  * to flip_solid_velocity_apply on every rank: V += dt Minv (J p). */
 int flip_solid_coupling_partial(flip_ctx *ctx, double jp[6]);
+/* Dependent rows (cells with phi_fluid >= 0 that carry a row) with a rigid-body entry found by the last
+ * flip_build_system.  Such rows rule out the elimination of the dependent rows (flip_set_system_options): a single
+ * context then solves the whole system; a slab context keeps the eliminated form, which the slab solver needs, and the
+ * ranks must agree on the sum of this count before they start the solve (flip_dist_solve does). */
+int flip_system_dependent_coupled(flip_ctx *ctx, int32_t *count);
 int flip_solid_velocity_apply(flip_ctx *ctx, float dt, const double jp_total[6]);
 int flip_pcg_dist_buffer(flip_ctx *ctx, int which, void **device_ptr, int64_t *count);
 int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, int precond);

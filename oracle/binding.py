@@ -107,6 +107,7 @@ class Oracle:
         L.orc_update_diff.argtypes = [i64, vp, vp, vp]
         L.orc_extrapolate_sweep.argtypes = [G, vp, vp, vp, vp]
         L.orc_add_gravity.argtypes = [i64, vp, vp, f32, f32]
+        L.orc_compute_cfl.restype = f32; L.orc_compute_cfl.argtypes = [i64, vp, vp, vp, vp, f32, vp, vp]
         L.orc_constrain_velocity.argtypes = [G, vp, f32] + [vp] * 9 + [C.c_int, vp, vp]
         L.orc_constrain_velocity.restype = None
         L.orc_set_num_threads(threads)
@@ -348,6 +349,15 @@ class Oracle:
         out = v.copy()
         self.lib.orc_add_gravity(self.B, _ptr(active), _ptr(out), np.float32(grav), np.float32(dt))
         return out
+
+    def compute_cfl(self, uvw, active, solid_translational=None):
+        """src/FluidSimulator.cpp:448-458 under the component-wise reading of the Vec3d maximum (see orc_compute_cfl).
+        Returns (dt, the three maxima)."""
+        m = np.zeros(3)
+        st = None if solid_translational is None else np.ascontiguousarray(solid_translational, np.float64)
+        dt = self.lib.orc_compute_cfl(self.B, _ptr(np.ascontiguousarray(active, np.uint8)), _ptr(uvw[0]), _ptr(uvw[1]), _ptr(uvw[2]),
+                                      np.float32(self.g.dx), _ptr(st), _ptr(m))
+        return float(dt), m
 
     def constrain_velocity(self, phi, bg, w, uvw, obj_vel=None):
         """src/FluidSimulator.cpp:1180-1321: faces with solid fraction 1 lose the normal component (obj_vel: the

@@ -1242,6 +1242,34 @@ ORC_EXPORT void orc_add_gravity(int64_t B, const uint8_t *active, double *v, flo
         if (active[c]) v[c] = v[c] - (double)(grav * dt);
 }
 
+/* src/FluidSimulator.cpp:448-458: compute_cfl.  The reference takes grid.velFront()->evalMinMax (OpenVDB 9, absent
+ * here: parity unpinned) and, per rigid body, std::max(maxVector, Abs(velTranslational)).  On Vec3d neither is a
+ * component-wise maximum in OpenVDB: evalMinMax keeps a value only when it exceeds the running maximum in ALL three
+ * components (math::cwiseGreaterThan, visiting order unspecified and threaded), and std::max uses the tuple's
+ * lexicographic operator<.  ASSUMED HERE, and what the device path computes: the component-wise maximum over the active
+ * voxels (signed, no absolute value: a purely falling fluid yields the rest of the frame), and the component-wise maximum
+ * with |V_translational| -- the one reading that does not depend on the order in which voxels are visited.  Types as
+ * the reference: float voxel size, double maxima, float epsilon 10e-37 widened, float result. */
+ORC_EXPORT float orc_compute_cfl(int64_t B, const uint8_t *active, const double *u, const double *v, const double *w, float voxel_size,
+                                 const double *solid_translational, double max_out[3]) {
+    double m[3] = { -1e300, -1e300, -1e300 };
+    for (int64_t c = 0; c < B; ++c)
+        if (active[c]) {
+            if (u[c] > m[0]) m[0] = u[c];
+            if (v[c] > m[1]) m[1] = v[c];
+            if (w[c] > m[2]) m[2] = w[c];
+        }
+    for (int a = 0; a < 3; ++a) {
+        if (m[a] == -1e300) m[a] = 0.0; /* no active voxel: evalMinMax returns zero */
+        if (solid_translational && fabs(solid_translational[a]) > m[a]) m[a] = fabs(solid_translational[a]);
+        if (max_out) max_out[a] = m[a];
+    }
+    const float epsilon = 10e-37f; /* src/FluidSimulator.cpp:32 */
+    double top = m[0] > m[1] ? m[0] : m[1];
+    top = top > m[2] ? top : m[2];
+    return (float)((double)voxel_size / (top + (double)epsilon));
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* constrain_velocity: src/FluidSimulator.cpp:1180-1247 (container) and :1249-1321 (rigid  */
 /* body).  On every face whose solid fraction is exactly 1 the sampled velocity loses its  */

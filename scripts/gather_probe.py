@@ -16,7 +16,7 @@ ctx.upload_scene(sc)
 radius = 1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0
 step = FlipSubstep(ctx, tol=1e-15, max_iter=20000, precond=PRECOND_MULTIGRID, constrain=True, advect=True, levelset_radius=radius)
 for _ in range(steps):
-    step.step(0.005)
+    step.step(float(os.environ.get('PROBE_DT', '0.001')))
 ctx.bin_particles(want_outside=False)
 s0 = ctx.gather_stats()
 def timeit(fn, reps=5):
@@ -38,4 +38,12 @@ ctx.bin_particles(want_outside=False)
 print(f"levelset {timeit(lambda: ctx.fluid_levelset_from_particles(radius))*1e3:.1f} us")
 ctx.update_diff()
 print(f"g2p {timeit(lambda: ctx.g2p(0.95))*1e3:.1f} us")
+# binning right after a real substep
+ctx2 = ctx
+for _ in range(3):
+    step.step(0.001)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ctx.synchronize(); torch.cuda.synchronize()
+    e0.record(); ctx.bin_particles(want_outside=False); e1.record(); e1.synchronize()
+    print(f"bin after a real substep {e0.elapsed_time(e1)*1e3:.1f} us")
 ctx.close()

@@ -29,6 +29,24 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_dist_library_exports_what_its_header_declares_and_calls_rccl():
+    """libflip_dist.so (the z-slab driver): every symbol include/flip_dist.h declares is exported and bound, and the product
+    itself imports the RCCL collectives (no compute calls here: loading needs no GPU)."""
+    import subprocess
+    from fluidsimulation_amd import dist_native
+    text = open(os.path.join(ROOT, "include", "flip_dist.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(flip_dist_[a-z0-9_]+)\s*\(", text)))
+    assert declared == sorted(dist_native.DIST_EXPORTS)
+    assert os.path.exists(dist_native.DIST_LIB_PATH), "build first: make -C fluidsimulation_amd/csrc"
+    lib = dist_native.load_dist_library()
+    assert not [s for s in declared if not hasattr(lib, s)]
+    syms = subprocess.run(["nm", "-D", dist_native.DIST_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for needed in ("ncclAllReduce", "ncclSend", "ncclRecv", "ncclCommInitRank", "ncclGroupStart"):
+        assert re.search(rf"\bU {needed}\b", syms), needed
+    assert ctypes.sizeof(dist_native.StepOptions) == 48
+
+
 def test_field_enum_matches_header():
     text = open(HEADER).read()
     enum = dict((m.group(1).lower(), int(m.group(2))) for m in re.finditer(r"FLIP_F_([A-Z_]+)\s*=\s*(\d+)", text))

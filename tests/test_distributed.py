@@ -308,7 +308,7 @@ def test_slab_solve_over_ranks_matches_the_global_solve(tmp_path, overlap, world
 # ------------------------------------------------------------------------------------------------
 # GPU: two ranks on the one device of the box, real kernels, gloo with host staging
 
-def _gpu_worker(rank, port, out_dir, precond, kind, overlap, full=False):
+def _gpu_worker(rank, port, out_dir, precond, kind, overlap, full=False, driver="python"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -317,7 +317,7 @@ def _gpu_worker(rank, port, out_dir, precond, kind, overlap, full=False):
     from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout, partition_scene
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=WORLD)
     try:
-        _gpu_rank_body(rank, out_dir, precond, kind, overlap, full)
+        _gpu_rank_body(rank, out_dir, precond, kind, overlap, full, driver)
     except BaseException:
         import traceback
         with open(os.path.join(out_dir, f"error_{rank}.txt"), "w") as f:
@@ -327,7 +327,7 @@ def _gpu_worker(rank, port, out_dir, precond, kind, overlap, full=False):
         dist.destroy_process_group()
 
 
-def _gpu_rank_body(rank, out_dir, precond, kind, overlap, full=False):
+def _gpu_rank_body(rank, out_dir, precond, kind, overlap, full=False, driver="python"):
     import torch
     from fluidsimulation_amd import FlipContext
     from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout, partition_scene
@@ -339,7 +339,14 @@ def _gpu_rank_body(rank, out_dir, precond, kind, overlap, full=False):
         with FlipContext(loc.desc(), device=0) as ctx:
             ctx.reserve_particles(2 * loc.pos.shape[0])
             ctx.upload_scene(loc)
-            step = DistributedSubstep(ctx, layout, Comm(), device=0, precond=precond, max_iter=20000, overlap=overlap, **_extras(sc, full))
+            if driver == "native":
+                # the C driver (libflip_dist.so) with its transport callbacks over gloo: RCCL refuses two ranks on one device
+                from fluidsimulation_amd.dist_native import NativeDistributedSubstep, TorchTransport
+                comm = Comm()
+                step = NativeDistributedSubstep(ctx, layout, comm, device=0, precond=precond, max_iter=20000, overlap=overlap,
+                                                transport=TorchTransport(comm, 0), **_extras(sc, full))
+            else:
+                step = DistributedSubstep(ctx, layout, Comm(), device=0, precond=precond, max_iter=20000, overlap=overlap, **_extras(sc, full))
             info = step.step(0.004)
             p = ctx.download("pressure")
             # after the exchange the set holds this rank's owned particles and fresh ghost copies
@@ -392,16 +399,18 @@ def _scene_gpu(kind="dam"):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precond,kind,overlap,full", [(0, "dam", 0, False), (1, "dam", 0, False), (1, "long", 0, False), (1, "dam", 8, False),
-                                                       (1, "long", 5, False), (0, "dam", 2, False), (1, "dam", 4, True),
-                                                       (1, "full_domain", 4, True)])
-def test_two_ranks_on_one_gpu_match_the_single_context_substep(tmp_path, precond, kind, overlap, full):
+@pytest.mark.parametrize("precond,kind,overlap,full,driver",
+                         [(0, "dam", 0, False, "python"), (1, "dam", 0, False, "python"), (1, "long", 0, False, "python"),
+                          (1, "dam", 8, False, "python"), (1, "long", 5, False, "python"), (0, "dam", 2, False, "python"),
+                          (1, "dam", 4, True, "python"), (1, "full_domain", 4, True, "python"),
+                          (1, "dam", 0, False, "native"), (1, "dam", 4, True, "native"), (1, "full_domain", 4, True, "native")])
+def test_two_ranks_on_one_gpu_match_the_single_context_substep(tmp_path, precond, kind, overlap, full, driver):
     import torch.multiprocessing as mp
     from fluidsimulation_amd import FlipContext, FlipSubstep
     from fluidsimulation_amd.distributed import SlabLayout
     port = _free_port()
     try:
-        mp.spawn(_gpu_worker, args=(port, str(tmp_path), precond, kind, overlap, full), nprocs=WORLD, join=True)
+        mp.spawn(_gpu_worker, args=(port, str(tmp_path), precond, kind, overlap, full, driver), nprocs=WORLD, join=True)
     except Exception:
         for r in range(WORLD):
             f = os.path.join(str(tmp_path), f"error_{r}.txt")
@@ -456,7 +465,7 @@ def _rigid_scene():
     return sc
 
 
-def _rigid_worker(rank, port, out_dir):
+def _rigid_worker(rank, port, out_dir, driver="python"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -472,8 +481,14 @@ def _rigid_worker(rank, port, out_dir):
         with FlipContext(loc.desc(), device=0) as ctx:
             ctx.reserve_particles(2 * loc.pos.shape[0])
             ctx.upload_scene(loc)
-            step = DistributedSubstep(ctx, layout, Comm(), device=0, precond=1, max_iter=20000, overlap=4, constrain=True,
-                                      rigid_body=True)
+            if driver == "native":
+                from fluidsimulation_amd.dist_native import NativeDistributedSubstep, TorchTransport
+                comm = Comm()
+                step = NativeDistributedSubstep(ctx, layout, comm, device=0, precond=1, max_iter=20000, overlap=4, constrain=True,
+                                                rigid_body=True, transport=TorchTransport(comm, 0))
+            else:
+                step = DistributedSubstep(ctx, layout, Comm(), device=0, precond=1, max_iter=20000, overlap=4, constrain=True,
+                                          rigid_body=True)
             info = step.step(0.004)
             pos, vel = ctx.download_particles()
             o0, o1 = layout.owned(rank)
@@ -491,7 +506,8 @@ def _rigid_worker(rank, port, out_dir):
 
 
 @pytest.mark.gpu
-def test_rigid_body_coupling_under_two_slabs_matches_the_single_context():
+@pytest.mark.parametrize("driver", ["python", "native"])
+def test_rigid_body_coupling_under_two_slabs_matches_the_single_context(driver):
     import tempfile
     import torch.multiprocessing as mp
     from fluidsimulation_amd import FlipContext, FlipSubstep
@@ -499,7 +515,7 @@ def test_rigid_body_coupling_under_two_slabs_matches_the_single_context():
     tmp = tempfile.mkdtemp()
     port = _free_port()
     try:
-        mp.spawn(_rigid_worker, args=(port, tmp), nprocs=WORLD, join=True)
+        mp.spawn(_rigid_worker, args=(port, tmp, driver), nprocs=WORLD, join=True)
     except Exception:
         for r in range(WORLD):
             f = os.path.join(tmp, f"error_{r}.txt")
@@ -531,3 +547,47 @@ def test_rigid_body_coupling_under_two_slabs_matches_the_single_context():
     dist_, idx = cKDTree(ref_pos).query(pos, k=1)
     assert dist_.max() < 1e-5 and np.array_equal(np.sort(idx), np.arange(ref_pos.shape[0]))
     assert np.abs(vel - ref_vel[idx]).max() / np.abs(ref_vel).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: the C driver over RCCL itself, one rank (all a one-GPU box can hold): a communicator of one rank, the slab path forced
+
+@pytest.mark.gpu
+def test_native_driver_over_rccl_with_one_rank():
+    """libflip_dist.so with its own RCCL communicator (ncclCommInitRank over one rank, ncclAllReduce after every CG kernel on
+    the context's stream).  Forced onto the slab path it reproduces the Python-driven split-phase substep bit for bit (the
+    same kernels in the same order); left alone it falls through to the single-context substep, also bit for bit."""
+    from fluidsimulation_amd import FlipContext, FlipSubstep, PRECOND_MULTIGRID
+    from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout
+    from fluidsimulation_amd.dist_native import NativeDistributedSubstep
+    sc = _scene_gpu("dam")
+    extras = _extras(sc, True)
+    layout = SlabLayout(sc.dims[2], 1, 0)
+
+    def run(make):
+        with FlipContext(sc.desc()) as ctx:
+            ctx.upload_scene(sc)
+            step = make(ctx)
+            infos = [step.step(0.004) for _ in range(2)]
+            pos, vel = ctx.download_particles()
+            p = ctx.download("pressure")
+            if hasattr(step, "close"):
+                step.close()
+        return infos, pos, vel, p
+
+    ref_i, ref_pos, ref_vel, ref_p = run(lambda c: FlipSubstep(c, precond=PRECOND_MULTIGRID, max_iter=20000, concurrent_solves=True, **extras))
+    py_i, py_pos, py_vel, py_p = run(lambda c: DistributedSubstep(c, layout, Comm(), device=0, precond=PRECOND_MULTIGRID, max_iter=20000, **extras))
+    nat_i, nat_pos, nat_vel, nat_p = run(lambda c: NativeDistributedSubstep(c, layout, Comm(), device=0, precond=PRECOND_MULTIGRID,
+                                                                            max_iter=20000, force_slab=True, **extras))
+    thru_i, thru_pos, thru_vel, thru_p = run(lambda c: NativeDistributedSubstep(c, layout, Comm(), device=0, precond=PRECOND_MULTIGRID,
+                                                                                max_iter=20000, **extras))
+    for i in nat_i + thru_i:
+        assert i["divergence"]["converged"] == 1 and i["density"]["converged"] == 1
+    # forced slab path over RCCL == the Python-driven split-phase loop
+    assert np.array_equal(nat_pos, py_pos) and np.array_equal(nat_vel, py_vel) and np.array_equal(nat_p, py_p)
+    assert [i["divergence"]["iterations"] for i in nat_i] == [i["divergence"]["iterations"] for i in py_i]
+    # fall-through == flip_solve_pair substep
+    assert np.array_equal(thru_pos, ref_pos) and np.array_equal(thru_vel, ref_vel) and np.array_equal(thru_p, ref_p)
+    # and the two paths agree to the solver tolerance
+    assert np.abs(nat_pos - ref_pos).max() < 1e-5
+    assert np.abs(nat_vel - ref_vel).max() / np.abs(ref_vel).max() < 1e-4

@@ -950,3 +950,117 @@ def test_iteration_cap_is_honoured_whatever_the_previous_solve_took(concurrent):
         again = free.step(0.004)
         for k in ("divergence", "density"):
             assert again[k]["converged"] == 1 and again[k]["rel_residual_2"] < RES_TOL, (k, again[k])
+
+
+def test_four_substeps_of_the_default_scene_follow_the_oracle():
+    """BASELINE config 1 (the cube drop at main.cpp's default 64^3) over FOUR whole substeps with the level set rebuilt
+    from the particles, both constrain_velocity calls and the RK3 advection switched on: the state a substep inherits
+    from the one before (valid flags, stale face weights, moved particles: src/FluidSimulator.cpp:343-345, 486-488) is
+    carried on the device and, independently, by the oracle; neither side is re-synchronised with the other.  After every
+    substep: labels and row count bit-exact, fluid level set equal to rounding, positions <= 1e-5 cell, velocities
+    <= 1e-4 relative."""
+    from fluidsimulation_amd import FlipSubstep, PRECOND_MULTIGRID
+    sc = scenes.cube_drop(64, ppc=4, seed=11, exact_levelset=False)
+    rng = np.random.default_rng(5)
+    sc.vel = rng.normal(0.0, 0.1, sc.pos.shape)
+    radius = 1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0    # src/FluidSource.cpp:67
+    dt = 0.004
+    o = Oracle(sc.desc(), threads=16)
+    st = fresh_state(sc, o)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        step = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, max_iter=20000, constrain=True, advect=True, levelset_radius=radius)
+        for k in range(4):
+            _, cell_start, perm, _ = o.bin_particles(st["pos"])
+            st["phi_fluid"] = o.fluid_levelset(st["pos"], cell_start, perm, sc.phi_solid, radius)
+            ref = o.substep(st, dt, max_iter=20000, constrain=True)
+            assert ref["err_div"] < RES_TOL and ref["err_den"] < RES_TOL
+            moved = o.advect_particles(st["pos"], ref["final_vel"], sc.phi_solid, dt)      # :426, before the displacements (:429)
+            new_pos = o.apply_displacements(moved, ref["disp"])
+            info = step.step(dt)
+            assert info["divergence"]["converged"] == 1 and info["density"]["converged"] == 1
+            assert info["divergence"]["rows"] == ref["n_rows"], k
+            assert np.array_equal(ctx.download("label"), ref["label"]), k
+            assert np.abs(ctx.download("phi_fluid") - st["phi_fluid"]).max() <= 1e-6 * float(sc.dx), k
+            for name, want in zip(("weight_u", "weight_v", "weight_w"), ref["w"]):
+                assert np.array_equal(ctx.download(name), want), (k, name)
+            pos, vel = ctx.download_particles()
+            assert np.abs(pos - new_pos).max() < POS_ATOL, k
+            assert rel_linf(vel, ref["new_vel"]) < VEL_RTOL, k
+            st = dict(st, pos=new_pos, vel=ref["new_vel"], w=ref["w"], valid=ref["valid"])
+
+
+def test_config_floating_ball_128_stages_against_the_oracle():
+    """BASELINE config 3 at full size (cube drop at 128^3 with the half-density sphere, 2.1 M particles): cell labels and row
+    numbers, the container's, the fluid's and the body's face fractions, and both assembled systems (stencil, diagonal,
+    right-hand side with the body's J^T V) against the 16-thread oracle, bit for bit except the J^T V sum; no CPU solve."""
+    sc = scenes.add_sphere(scenes.cube_drop(128, ppc=8, seed=12345, exact_levelset=False), density=500.0,
+                           vel=(0.02, -0.3, 0.01, 0.2, 0.0, -0.1))
+    rng = np.random.default_rng(8)
+    sc.vel = rng.normal(0.0, 0.15, sc.pos.shape)
+    dt = 0.004
+    o = Oracle(sc.desc(), threads=16)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        ctx.bin_particles(); ctx.p2g(); ctx.mark_valid_from_active(); ctx.extrapolate(2); ctx.update_prev(); ctx.add_forces(dt)
+        n_rows = ctx.index_cells(); ctx.face_fractions(); ctx.density()
+        _, cell_start, _ = ctx.download_binning()
+        uvw = [ctx.download(nm) for nm in ("vel_u", "vel_v", "vel_w")]
+        dens = ctx.download("density")
+        z32 = lambda: np.zeros(o.shape, np.float32)  # noqa: E731
+        label, index, want_rows = o.index_cells(o.particle_mask(cell_start, 1), sc.phi_fluid, sc.phi_solid, [z32(), z32(), z32()])
+        assert n_rows == want_rows and n_rows > 200000
+        assert np.array_equal(ctx.download("label"), label) and np.array_equal(ctx.download("row_index"), index)
+        ow = o.face_fractions(sc.phi_object, sc.phi_object_bg, o.weight_mask(sc.phi_object, sc.phi_object_bg))
+        wm = o.weight_mask(sc.phi_fluid, sc.phi_fluid_bg)
+        fw = o.face_fractions(sc.phi_fluid, sc.phi_fluid_bg, wm)
+        w = o.face_fractions(sc.phi_solid, sc.phi_solid_bg, wm)
+        for name, want in zip(("obj_weight_u", "obj_weight_v", "obj_weight_w"), ow):
+            assert np.array_equal(ctx.download(name), want), name
+        o.combine_weights(w, ow)
+        for name, want in zip(("weight_u", "weight_v", "weight_w"), w):
+            assert np.array_equal(ctx.download(name), want), name
+        for name, want in zip(("fluid_weight_u", "fluid_weight_v", "fluid_weight_w"), fw):
+            assert np.array_equal(ctx.download(name), want), name
+        lab = label.astype(bool)
+        # divergence system with the rank-6 coupling's right-hand side
+        off, diag, rhs = o.build_system(0, dt, label, sc.phi_fluid, sc.phi_solid, w, uvw=uvw)
+        J = o.build_J(index, ow, sc.object_com)
+        b = o.to_csr(index, off, diag, rhs)[3] - J.T @ np.asarray(sc.object_vel, np.float64)
+        ctx.build_system(SOLVE_DIVERGENCE, dt)
+        goff, gdiag, grhs = ctx.download_system()
+        assert np.array_equal(gdiag, diag) and np.array_equal(goff, off)
+        assert np.allclose(grhs[lab], b, rtol=0, atol=1e-18 + 1e-13 * np.abs(b).max())
+        # density system (no coupling: src/FluidSimulator.cpp:846-849)
+        off2, diag2, rhs2 = o.build_system(1, dt, label, sc.phi_fluid, sc.phi_solid, w, density=dens)
+        ctx.build_system(SOLVE_DENSITY, dt)
+        goff, gdiag, grhs = ctx.download_system()
+        assert np.array_equal(gdiag, diag2) and np.array_equal(goff, off2) and np.array_equal(grhs, rhs2)
+
+
+def test_velocity_maximum_and_cfl_against_numpy_and_the_oracle():
+    """flip_velocity_max (the reduction of compute_cfl, src/FluidSimulator.cpp:448-458) is the plain component-wise maximum
+    over the active voxels, bit for bit, the allocation-free twin agrees, and the oracle's compute_cfl gives the substep
+    size the host class derives from it."""
+    from fluidsimulation_amd import FlipSubstep, PRECOND_MULTIGRID
+    sc = scenes.dam_break(32, ppc=4, seed=9)
+    rng = np.random.default_rng(2)
+    sc.vel = rng.normal(0.0, 0.3, sc.pos.shape)
+    o = Oracle(sc.desc())
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        step = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, max_iter=20000)
+        for _ in range(2):
+            step.step(0.004)
+            uvw = [ctx.download(nm) for nm in ("vel_u", "vel_v", "vel_w")]
+            active = ctx.download("active").astype(bool)
+            want = np.array([a[active].max() for a in uvw])
+            got = np.asarray(ctx.velocity_max())
+            assert np.array_equal(got, want)
+            assert np.array_equal(np.asarray(ctx.velocity_max_static()), want)
+            dt, m = o.compute_cfl(uvw, active)
+            assert np.array_equal(m, want)
+            assert dt == np.float32(np.float64(np.float32(sc.dx)) / (want.max() + np.float64(np.float32(10e-37))))
+            body = np.array([0.0, -2.0 * want.max() - 1.0, 0.0])
+            dt_b, m_b = o.compute_cfl(uvw, active, body)
+            assert m_b[1] == -body[1] and dt_b < dt
