@@ -49,6 +49,8 @@ FIELDS = {
     "active": (25, np.uint8), "label": (26, np.uint8), "row_index": (27, np.int32), "band": (28, np.uint8),
     "obj_weight_u": (29, np.float32), "obj_weight_v": (30, np.float32), "obj_weight_w": (31, np.float32),
     "phi_object": (32, np.float32),
+    "vel_back_u": (33, np.float64), "vel_back_v": (34, np.float64), "vel_back_w": (35, np.float64),
+    "valid_back_u": (36, np.uint8), "valid_back_v": (37, np.uint8), "valid_back_w": (38, np.uint8),
 }
 
 SOLVE_DIVERGENCE, SOLVE_DENSITY = 0, 1
@@ -60,7 +62,7 @@ EXPORTS = [
     "flip_particles_upload", "flip_particles_download", "flip_particles_download_mass", "flip_particles_count", "flip_bin_particles",
     "flip_binning_download", "flip_field_upload", "flip_field_download", "flip_field_bytes", "flip_p2g", "flip_gather_stats", "flip_set_gather_mode", "flip_g2p",
     "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_fluid_levelset_from_particles", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
-    "flip_update_prev", "flip_update_diff", "flip_velocity_max", "flip_velocity_max_static", "flip_index_cells", "flip_face_fractions",
+    "flip_update_prev", "flip_update_diff", "flip_swap_velocity_buffers", "flip_swap_valid_masks", "flip_velocity_max", "flip_velocity_max_static", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_redistribute_overdense", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
     "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_project_velocity",
     "flip_project_displacement", "flip_set_slab", "flip_solid_coupling_partial", "flip_solid_velocity_apply", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
@@ -113,6 +115,8 @@ def load_library(path: str = LIB_PATH):
         "flip_add_forces": (C.c_int, [vp, f32]),
         "flip_update_prev": (C.c_int, [vp]),
         "flip_update_diff": (C.c_int, [vp]),
+        "flip_swap_velocity_buffers": (C.c_int, [vp]),
+        "flip_swap_valid_masks": (C.c_int, [vp]),
         "flip_velocity_max": (C.c_int, [vp, P(f64)]),
         "flip_velocity_max_static": (C.c_int, [vp, P(f64)]),
         "flip_index_cells": (C.c_int, [vp, P(i32)]),
@@ -289,6 +293,12 @@ class FlipContext:
 
     def update_diff(self):
         self._check(self.lib.flip_update_diff(self.h))
+
+    def swap_velocity_buffers(self):
+        self._check(self.lib.flip_swap_velocity_buffers(self.h))
+
+    def swap_valid_masks(self):
+        self._check(self.lib.flip_swap_valid_masks(self.h))
 
     def velocity_max(self):
         out = (C.c_double * 3)()

@@ -251,6 +251,16 @@ extern "C" int flip_synchronize(flip_ctx *ctx) {
     FLIP_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
+extern "C" int flip_swap_velocity_buffers(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx, "null context");
+    for (int a = 0; a < 3; ++a) std::swap(ctx->vel[0][a], ctx->vel[1][a]);
+    return 0;
+}
+extern "C" int flip_swap_valid_masks(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx, "null context");
+    for (int a = 0; a < 3; ++a) std::swap(ctx->valid[0][a], ctx->valid[1][a]);
+    return 0;
+}
 extern "C" int flip_get_stream(const flip_ctx *ctx, void **stream, int *device) {
     if (!ctx || !stream) return 1;
     *stream = (void *)ctx->stream;
@@ -290,6 +300,8 @@ static int field_ptr(flip_ctx *c, int field, void **ptr, int *elem) {
     case FLIP_F_DENSITY: p = c->density; es = 4; break;
     case FLIP_F_PRESSURE: p = c->x; es = 8; break;
     case FLIP_F_VALID_U: case FLIP_F_VALID_V: case FLIP_F_VALID_W: p = c->valid[0][field - FLIP_F_VALID_U]; es = 1; break;
+    case FLIP_F_VEL_BACK_U: case FLIP_F_VEL_BACK_V: case FLIP_F_VEL_BACK_W: p = c->vel[1][field - FLIP_F_VEL_BACK_U]; es = 8; break;
+    case FLIP_F_VALID_BACK_U: case FLIP_F_VALID_BACK_V: case FLIP_F_VALID_BACK_W: p = c->valid[1][field - FLIP_F_VALID_BACK_U]; es = 1; break;
     case FLIP_F_ACTIVE: p = c->active; es = 1; break;
     case FLIP_F_LABEL: p = c->label; es = 1; break;
     case FLIP_F_ROW_INDEX: p = c->row_index; es = 4; break;

@@ -31,6 +31,7 @@ public:
     flipvdb::Vec3dGrid::Ptr downloadVec3d(int field_x);
     void uploadVec3d(int field_x, const flipvdb::Vec3dGrid &grid);
     flipvdb::MaskGrid::Ptr downloadMask(int field);
+    void uploadMask(int field, const flipvdb::MaskGrid &grid);
 
 private:
     flip_ctx *_ctx = nullptr;

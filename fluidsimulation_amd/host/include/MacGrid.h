@@ -18,18 +18,29 @@ public:
     MacGrid(flipvdb::Transform::Ptr i2w_transform, float voxel_size);
     ~MacGrid();
 
+    using StaggeredSampler = flipvdb::tools::GridSampler<flipvdb::Vec3dGrid::Accessor, flipvdb::tools::StaggeredBoxSampler>;
+    using Sampler = flipvdb::tools::GridSampler<flipvdb::Vec3dGrid::Accessor, flipvdb::tools::BoxSampler>;
+
     void updatePreviousVelocityBuffer();   // src/MacGrid.cpp:55-61
     void updateDiffBuffers();              // src/MacGrid.cpp:63
 
+    // src/MacGrid.cpp:65-70: the front and back buffers change places (pointer swaps on the device)
+    void swapVelocityBuffers();
+    void swapValidMasks();
+
     // Getters (headers/MacGrid.h:47-66): snapshots of the device buffers.
     flipvdb::Vec3dGrid::Ptr velFront();
+    flipvdb::Vec3dGrid::Ptr velBack();
     flipvdb::Vec3dGrid::Ptr velPrev();
     flipvdb::Vec3dGrid::Ptr velDiff();
     flipvdb::FloatGrid::Ptr densityGrid();
     flipvdb::Vec3dGrid::Ptr displacementGrid();
     flipvdb::MaskGrid::Ptr validUFront();
+    flipvdb::MaskGrid::Ptr validUBack();
     flipvdb::MaskGrid::Ptr validVFront();
+    flipvdb::MaskGrid::Ptr validVBack();
     flipvdb::MaskGrid::Ptr validWFront();
+    flipvdb::MaskGrid::Ptr validWBack();
     flipvdb::FloatGrid::Ptr uWeights();
     flipvdb::FloatGrid::Ptr vWeights();
     flipvdb::FloatGrid::Ptr wWeights();
@@ -37,9 +48,25 @@ public:
     flipvdb::FloatGrid::Ptr vFluidWeights();
     flipvdb::FloatGrid::Ptr wFluidWeights();
 
-    // headers/MacGrid.h:73-86 on a snapshot returned by velFront()
+    // headers/MacGrid.h:73-86: through a sampler built on a snapshot's accessor, as the reference's callers do
+    // (StaggeredSampler s(grid.velFront()->getAccessor(), *transform)) ...
+    inline flipvdb::Vec3d velInterpolatedI(StaggeredSampler &sampler, flipvdb::Vec3d isPoint) const { return sampler.isSample(isPoint); }
+    inline flipvdb::Vec3d velInterpolatedI(StaggeredSampler &sampler, double x, double y, double z) const {
+        return sampler.isSample(flipvdb::Vec3d(x, y, z));
+    }
+    inline flipvdb::Vec3d velInterpolatedW(StaggeredSampler &sampler, flipvdb::Vec3d wsPoint) const { return sampler.wsSample(wsPoint); }
+    inline flipvdb::Vec3d velInterpolatedW(StaggeredSampler &sampler, double x, double y, double z) const {
+        return sampler.wsSample(flipvdb::Vec3d(x, y, z));
+    }
+    // ... or directly on a snapshot returned by velFront()
     flipvdb::Vec3d velInterpolatedI(const flipvdb::Vec3dGrid &snapshot, flipvdb::Vec3d isPoint) const;
     flipvdb::Vec3d velInterpolatedW(const flipvdb::Vec3dGrid &snapshot, flipvdb::Vec3d wsPoint) const;
+
+    // headers/MacGrid.h:91-94: a caller's grid becomes the back buffer (uploaded; the box must be the device's)
+    void setValidUBack(flipvdb::MaskGrid::Ptr mask);
+    void setValidVBack(flipvdb::MaskGrid::Ptr mask);
+    void setValidWBack(flipvdb::MaskGrid::Ptr mask);
+    void setVelBack(flipvdb::Vec3dGrid::Ptr vel_back);
 
     inline float voxelSize() { return _voxel_size; };
 

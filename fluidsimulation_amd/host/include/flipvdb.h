@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdint>
 #include <memory>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -125,6 +126,7 @@ public:
         explicit Accessor(DenseGrid *g): _g(g) {}
         const T &getValue(const Coord &c) const { return _g->getValue(c); }
         void setValue(const Coord &c, const T &v) { _g->setValue(c, v); _g->_edited = true; }
+        const DenseGrid *grid() const { return _g; }
     private:
         DenseGrid *_g;
     };
@@ -174,6 +176,8 @@ using Vec3fGrid = Vec3dGrid; // Vec3f is Vec3d here
 float sampleBox(const FloatGrid &grid, const Vec3d &index_point);
 // openvdb::tools::StaggeredBoxSampler: component c sampled at index_point + e_c / 2.
 Vec3d sampleStaggered(const Vec3dGrid &grid, const Vec3d &index_point);
+// openvdb::tools::BoxSampler on a Vec3d grid: all three components at index_point.
+Vec3d sampleCollocated(const Vec3dGrid &grid, const Vec3d &index_point);
 
 // Narrow-band signed distance grids, negative inside (the OpenVDB convention), world units, clipped to
 // +-half_width voxels; the dense box is the band's bounding box.
@@ -219,6 +223,23 @@ typename GridT::Ptr createLevelSetSphere(float radius, const Vec3d &center, floa
     return grid;
 }
 inline FloatGrid::Ptr csgUnionCopy(const FloatGrid &a, const FloatGrid &b) { return flipvdb::csgUnionCopy(a, b); }
+// openvdb::tools::GridSampler<Accessor, Sampler> as headers/MacGrid.h:34-37 instantiates it: index- and world-space
+// samples of a Vec3d grid through one of the two samplers below
+struct BoxSampler {};
+struct StaggeredBoxSampler {};
+template <class AccessorT, class SamplerT>
+class GridSampler {
+public:
+    GridSampler(const AccessorT &accessor, const flipvdb::Transform &xform): _grid(accessor.grid()), _xform(xform) {}
+    Vec3d isSample(const Vec3d &index_point) const {
+        if (std::is_same<SamplerT, StaggeredBoxSampler>::value) return flipvdb::sampleStaggered(*_grid, index_point);
+        return flipvdb::sampleCollocated(*_grid, index_point);
+    }
+    Vec3d wsSample(const Vec3d &world_point) const { return isSample(_xform.worldToIndex(world_point)); }
+private:
+    const Vec3dGrid *_grid;
+    flipvdb::Transform _xform;
+};
 }
 namespace io {
 // openvdb::io::File (main.cpp:111-113,193-199).  The .vdb container format is OpenVDB's own and not reproduced: write()

@@ -63,3 +63,12 @@ MaskGrid::Ptr FlipDevice::downloadMask(int field) {
     check(flip_field_download(_ctx, field, g->raw()), "flip_field_download");
     return g;
 }
+
+void FlipDevice::uploadMask(int field, const MaskGrid &grid) {
+    std::vector<uint8_t> tmp((size_t)cells());
+    size_t q = 0;
+    for (int k = _box.mn[2]; k <= _box.mx[2]; ++k)
+        for (int j = _box.mn[1]; j <= _box.mx[1]; ++j)
+            for (int i = _box.mn[0]; i <= _box.mx[0]; ++i) tmp[q++] = grid.getValue(Coord(i, j, k)) ? 1 : 0;
+    check(flip_field_upload(_ctx, field, tmp.data()), "flip_field_upload");
+}

@@ -10,6 +10,13 @@ MacGrid::~MacGrid() {}
 void MacGrid::updatePreviousVelocityBuffer() { _device->check(flip_update_prev(_device->ctx()), "flip_update_prev"); }
 void MacGrid::updateDiffBuffers() { _device->check(flip_update_diff(_device->ctx()), "flip_update_diff"); }
 
+void MacGrid::swapVelocityBuffers() {
+    push(); // pending writes belong to the buffer that is the front one now
+    _device->check(flip_swap_velocity_buffers(_device->ctx()), "flip_swap_velocity_buffers");
+    _front_snapshot.reset();
+}
+void MacGrid::swapValidMasks() { _device->check(flip_swap_valid_masks(_device->ctx()), "flip_swap_valid_masks"); }
+
 Vec3dGrid::Ptr MacGrid::velFront() {
     if (_front_snapshot && _front_snapshot->edited()) return _front_snapshot; // unsaved writes: hand the same grid out again
     _front_snapshot = _device->downloadVec3d(FLIP_F_VEL_U);
@@ -72,6 +79,14 @@ void MacGrid::addToVelInterpolated(Accessor &acc, float x, float y, float z, Vec
 void MacGrid::setVelInterpolated(Accessor &acc, float x, float y, float z, Vec3d value) {
     spread(*_i2w_transform, x, y, z, value, [&](const Coord &c, const Vec3d &share) { acc.setValue(c, share); });
 }
+Vec3dGrid::Ptr MacGrid::velBack() { return _device->downloadVec3d(FLIP_F_VEL_BACK_U); }
+MaskGrid::Ptr MacGrid::validUBack() { return _device->downloadMask(FLIP_F_VALID_BACK_U); }
+MaskGrid::Ptr MacGrid::validVBack() { return _device->downloadMask(FLIP_F_VALID_BACK_V); }
+MaskGrid::Ptr MacGrid::validWBack() { return _device->downloadMask(FLIP_F_VALID_BACK_W); }
+void MacGrid::setValidUBack(MaskGrid::Ptr mask) { _device->uploadMask(FLIP_F_VALID_BACK_U, *mask); }
+void MacGrid::setValidVBack(MaskGrid::Ptr mask) { _device->uploadMask(FLIP_F_VALID_BACK_V, *mask); }
+void MacGrid::setValidWBack(MaskGrid::Ptr mask) { _device->uploadMask(FLIP_F_VALID_BACK_W, *mask); }
+void MacGrid::setVelBack(Vec3dGrid::Ptr vel_back) { _device->uploadVec3d(FLIP_F_VEL_BACK_U, *vel_back); }
 Vec3dGrid::Ptr MacGrid::velPrev() { return _device->downloadVec3d(FLIP_F_PREV_U); }
 Vec3dGrid::Ptr MacGrid::velDiff() { return _device->downloadVec3d(FLIP_F_DIFF_U); }
 FloatGrid::Ptr MacGrid::densityGrid() { return _device->downloadFloat(FLIP_F_DENSITY, 0.f); }

@@ -32,6 +32,12 @@ Vec3d sampleStaggered(const Vec3dGrid &grid, const Vec3d &p) {
     return out;
 }
 
+Vec3d sampleCollocated(const Vec3dGrid &grid, const Vec3d &p) {
+    Vec3d out;
+    for (int c = 0; c < 3; ++c) out[c] = trilinear<double>(p, [&](int i, int j, int k) { return grid.getValue(Coord(i, j, k))[c]; });
+    return out;
+}
+
 namespace {
 // signed distance (index units) to an axis-aligned box, negative inside
 double boxDistance(const Vec3d &p, const Vec3d &lo, const Vec3d &hi) {

@@ -77,7 +77,13 @@ enum flip_field {
     FLIP_F_OBJ_WEIGHT_V = 30,
     FLIP_F_OBJ_WEIGHT_W = 31,
     FLIP_F_PHI_OBJECT = 32, /* [f32]  SolidObject::levelSet() of the coupled rigid body    */
-    FLIP_F_COUNT = 33
+    FLIP_F_VEL_BACK_U = 33, /* [f64]  MacGrid::velBack(), component-wise (headers/MacGrid.h:48) */
+    FLIP_F_VEL_BACK_V = 34,
+    FLIP_F_VEL_BACK_W = 35,
+    FLIP_F_VALID_BACK_U = 36, /* [u8] MacGrid::validUBack() / VBack / WBack (headers/MacGrid.h:54-58) */
+    FLIP_F_VALID_BACK_V = 37,
+    FLIP_F_VALID_BACK_W = 38,
+    FLIP_F_COUNT = 39
 };
 
 enum flip_solve_kind {
@@ -193,6 +199,9 @@ int flip_add_forces(flip_ctx *ctx, float dt);
 /* MacGrid::updatePreviousVelocityBuffer / updateDiffBuffers (src/MacGrid.cpp:55-63). */
 int flip_update_prev(flip_ctx *ctx);
 int flip_update_diff(flip_ctx *ctx);
+/* MacGrid::swapVelocityBuffers / swapValidMasks (src/MacGrid.cpp:65-70): pointer swaps of the front and back buffers. */
+int flip_swap_velocity_buffers(flip_ctx *ctx);
+int flip_swap_valid_masks(flip_ctx *ctx);
 /* max over the box of each velocity component (Grid::evalMinMax in compute_cfl,
  * src/FluidSimulator.cpp:448-458). */
 int flip_velocity_max(flip_ctx *ctx, double out_max[3]);

@@ -1064,3 +1064,23 @@ def test_velocity_maximum_and_cfl_against_numpy_and_the_oracle():
             body = np.array([0.0, -2.0 * want.max() - 1.0, 0.0])
             dt_b, m_b = o.compute_cfl(uvw, active, body)
             assert m_b[1] == -body[1] and dt_b < dt
+
+
+def test_buffer_swaps_exchange_front_and_back():
+    """MacGrid::swapVelocityBuffers / swapValidMasks (src/MacGrid.cpp:65-70) on the device buffers."""
+    sc = scenes.cube_drop(16, ppc=2, seed=3)
+    rng = np.random.default_rng(1)
+    with FlipContext(sc.desc()) as ctx:
+        shape = ctx.download("vel_u").shape
+        front = [rng.normal(size=shape) for _ in range(3)]
+        back = [rng.normal(size=shape) for _ in range(3)]
+        vf = [(rng.random(shape) < 0.5).astype(np.uint8) for _ in range(3)]
+        vb = [(rng.random(shape) < 0.5).astype(np.uint8) for _ in range(3)]
+        for a, n in enumerate("uvw"):
+            ctx.upload(f"vel_{n}", front[a]); ctx.upload(f"vel_back_{n}", back[a])
+            ctx.upload(f"valid_{n}", vf[a]); ctx.upload(f"valid_back_{n}", vb[a])
+        ctx.swap_velocity_buffers()
+        ctx.swap_valid_masks()
+        for a, n in enumerate("uvw"):
+            assert np.array_equal(ctx.download(f"vel_{n}"), back[a]) and np.array_equal(ctx.download(f"vel_back_{n}"), front[a])
+            assert np.array_equal(ctx.download(f"valid_{n}"), vb[a]) and np.array_equal(ctx.download(f"valid_back_{n}"), vf[a])

@@ -161,6 +161,39 @@ def test_macgrid_setters_are_exported():
         assert sym in out, sym
 
 
+def test_macgrid_buffer_members_of_the_reference_header(tmp_path):
+    """headers/MacGrid.h:43-44 (swaps), :48-58 (back-buffer getters), :73-86 (StaggeredSampler-typed interpolation) and
+    :91-94 (back-buffer setters): exported, and a caller written against the reference's header spelling compiles."""
+    out = subprocess.run(["nm", "-DC", "--defined-only", LIB], check=True, capture_output=True, text=True).stdout
+    for sym in ("MacGrid::swapVelocityBuffers()", "MacGrid::swapValidMasks()", "MacGrid::velBack()", "MacGrid::validUBack()",
+                "MacGrid::validVBack()", "MacGrid::validWBack()", "MacGrid::setVelBack(", "MacGrid::setValidUBack(",
+                "MacGrid::setValidVBack(", "MacGrid::setValidWBack("):
+        assert sym in out, sym
+    caller = tmp_path / "caller.cpp"
+    caller.write_text("""
+#include <openvdb/openvdb.h>
+#include "MacGrid.h"
+openvdb::Vec3d probe(MacGrid &grid, openvdb::math::Transform::Ptr xform) {
+    openvdb::Vec3dGrid::Ptr front = grid.velFront();
+    MacGrid::Accessor acc = front->getAccessor();
+    MacGrid::StaggeredSampler sampler(acc, *xform);
+    openvdb::Vec3d v = grid.velInterpolatedI(sampler, openvdb::Vec3d(1.0, 2.0, 3.0));
+    v = v + grid.velInterpolatedI(sampler, 1.0, 2.0, 3.0) + grid.velInterpolatedW(sampler, openvdb::Vec3d(0.1, 0.2, 0.3))
+        + grid.velInterpolatedW(sampler, 0.1, 0.2, 0.3);
+    grid.setVelBack(grid.velBack());
+    grid.setValidUBack(grid.validUBack());
+    grid.setValidVBack(grid.validVBack());
+    grid.setValidWBack(grid.validWBack());
+    grid.swapVelocityBuffers();
+    grid.swapValidMasks();
+    return v;
+}
+""")
+    r = subprocess.run(["g++", "-std=c++20", "-fsyntax-only", "-I", os.path.join(HOST, "compat"), "-I", os.path.join(HOST, "include"),
+                        str(caller)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_reference_main_cpp_runs_two_frames(tmp_path):
     """The binary built from the reference's main.cpp (scene of main.cpp:53-99: container, floating sphere, cube source
