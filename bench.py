@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--sequential-solves", action="store_true",
                     help="N = 1: divergence solve, projection, density solve one after the other (the reference's order) instead "
                          "of both solves side by side on two streams")
+    ap.add_argument("--warm-start", action="store_true",
+                    help="flip_set_warm_start 1: a solve starts from the previous substep's solution instead of zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=8, help="CG iterations per timed repetition on the CPU (5 repetitions, median)")
     return ap.parse_args()
@@ -357,6 +359,8 @@ def main():
     ctx = FlipContext(sc.desc(), device=local)
     ctx.reserve_particles(sc.pos.shape[0] * 5 // 4 + 4096)
     ctx.upload_scene(sc)
+    if args.warm_start:
+        ctx.set_warm_start(True)
     radius = 1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0   # src/FluidSource.cpp:67
     extra = {} if args.hot_path_only else dict(constrain=True, advect=True, levelset_radius=radius)
     overlap = 0
@@ -526,6 +530,9 @@ def main():
             "config": {"workload": workload, "cells": tot_cells, "particles": tot_particles, "rows": tot_rows, "parallelism": parallelism},
             "hot_path_only": hot,
             "pcg": {"iterations_per_step": iters / args.steps, "seconds_per_step": pcg_s / args.steps,
+                    "warm_start": args.warm_start and not slabs,
+                    "iterations_to_pcgsolver_rule_per_step": (sum(q["iterations_inf"] for q in solves) / args.steps
+                                                              if all(q["iterations_inf"] >= 0 for q in solves) else None),
                     "effective_GBps": pcg_gbs, "pct_hbm_peak": 100.0 * pcg_gbs / HBM_PEAK_GBS,
                     "bytes_per_row_per_iteration": it_bytes, "rows_this_rank": rows,
                     "converged": all(s["converged"] == 1 for s in solves)},

@@ -29,7 +29,7 @@ class PcgInfo(C.Structure):
     _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("rows", C.c_int32), ("cg_rows", C.c_int32),
                 ("active_chunks", C.c_int32), ("rel_residual_2", C.c_double), ("rhs_norm_2", C.c_double),
                 ("seconds", C.c_double), ("spmv_seconds", C.c_double), ("spmv_launches", C.c_int32),
-                ("dependent_rows", C.c_int32), ("reserved", C.c_int32)]
+                ("dependent_rows", C.c_int32), ("iterations_inf", C.c_int32), ("rel_residual_inf", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -64,7 +64,7 @@ EXPORTS = [
     "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_fluid_levelset_from_particles", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
     "flip_update_prev", "flip_update_diff", "flip_swap_velocity_buffers", "flip_swap_valid_masks", "flip_velocity_max", "flip_velocity_max_static", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_redistribute_overdense", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
-    "flip_set_system_options", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_project_velocity",
+    "flip_set_system_options", "flip_set_warm_start", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_project_velocity",
     "flip_project_displacement", "flip_set_slab", "flip_solid_coupling_partial", "flip_solid_velocity_apply", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
     "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish", "flip_set_slab_overlap",
     "flip_pcg_dist_precondition", "flip_pcg_dist_combine", "flip_particles_reserve", "flip_particles_pack",
@@ -127,6 +127,7 @@ def load_library(path: str = LIB_PATH):
         "flip_solid_object_velocity": (C.c_int, [vp, P(f64)]),
         "flip_build_system": (C.c_int, [vp, C.c_int, f32]),
         "flip_set_system_options": (C.c_int, [vp, C.c_int, C.c_int]),
+        "flip_set_warm_start": (C.c_int, [vp, C.c_int]),
         "flip_system_download": (C.c_int, [vp, vp, vp, vp]),
         "flip_pcg_solve": (C.c_int, [vp, f64, i32, C.c_int, P(PcgInfo)]),
         "flip_apply_operator": (C.c_int, [vp, vp, vp]),
@@ -352,6 +353,10 @@ class FlipContext:
     def set_system_options(self, drop_null_rows: bool = True, eliminate_dependent_rows: bool = True):
         self._check(self.lib.flip_set_system_options(self.h, 1 if drop_null_rows else 0,
                                                      1 if eliminate_dependent_rows else 0))
+
+    def set_warm_start(self, on: bool = True):
+        """Start each solve from the last converged solution of the same kind (see flip_set_warm_start)."""
+        self._check(self.lib.flip_set_warm_start(self.h, 1 if on else 0))
 
     def download_system(self):
         off = np.empty((6,) + self.shape, dtype=np.float64)

@@ -109,7 +109,7 @@ void flip_free_system(flip_ctx *c) {
 
 void flip_swap_systems(flip_ctx *c) {
     flip_system_set &o = c->other;
-    std::swap(c->sys_kind, o.sys_kind); std::swap(c->sys_dt, o.sys_dt); std::swap(c->sys_s2, o.sys_s2);
+    std::swap(c->sys_kind, o.sys_kind); std::swap(c->x_kind, o.x_kind); std::swap(c->sys_dt, o.sys_dt); std::swap(c->sys_s2, o.sys_s2);
     std::swap(c->sys_coupled, o.sys_coupled); std::swap(c->sys_eliminated, o.sys_eliminated);
     for (int a = 0; a < 3; ++a) { std::swap(c->term[a], o.term[a]); std::swap(c->cg_c[a], o.cg_c[a]); }
     std::swap(c->flags, o.flags); std::swap(c->diag, o.diag); std::swap(c->invdiag, o.invdiag); std::swap(c->rhs, o.rhs);
@@ -324,6 +324,7 @@ extern "C" int flip_field_upload(flip_ctx *ctx, int field, const void *host) {
     FLIP_REQUIRE(field_ptr(ctx, field, &p, &es) == 0, "flip_field_upload: unknown field");
     FLIP_CHECK(hipSetDevice(ctx->device));
     if (field == FLIP_F_PHI_FLUID || field == FLIP_F_DENSITY) ctx->density_valid = false;
+    if (field == FLIP_F_PRESSURE) ctx->x_kind = -1; // no longer the solver's own result
     FLIP_CHECK(hipMemcpyAsync(p, host, (size_t)ctx->B * es, hipMemcpyHostToDevice, ctx->stream));
     FLIP_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;

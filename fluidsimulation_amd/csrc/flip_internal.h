@@ -36,6 +36,11 @@ struct flip_pcg_scalars {
     float creg;          // the coupling value of the rows flagged regular (see flip_ctx::reg)
     int32_t fused;       // the update kernel also pre-smooths (k_pcg_update_pre): the residual alternates between two
                          // buffers, the current one being number it_a & 1
+    int32_t warm;        // the solve started from a guess: |b|^2 comes from partial slot 9, not from |r_0|^2
+    // The stopping rule of headers/pcgsolver/pcg_solver.h:241-258, watched beside Eigen's: max|r| <= 1e-12 max|b|.
+    int32_t track_inf;   // partial slots 10 (max|b|, written once) and 11 (max|r| of the last update) are maintained
+    int32_t it_inf;      // iterations after which that rule first held (-1: not yet)
+    double binf, rinf;   // max|b|, max|r| as of the last direction kernel
 };
 
 // Packed particle record read by the gather kernels (P2G, density): one 64-byte line per particle instead of
@@ -74,6 +79,7 @@ struct flip_mg_level {
 // exchanges the two sets, so every kernel wrapper keeps reading the context's own fields.
 struct flip_system_set {
     int sys_kind = -1;
+    int x_kind = -1;
     float sys_dt = 0.f;
     double sys_s2 = 1.0;
     bool sys_coupled = false, sys_eliminated = false;
@@ -157,6 +163,9 @@ struct flip_ctx {
 
     // ---- assembled system + PCG ----
     int sys_kind = -1;
+    int x_kind = -1;                // kind of the system whose converged solution x holds (-1: none); the next solve of
+                                    // that kind on this set of arrays may start from it (warm_start)
+    bool warm_start = false;        // flip_set_warm_start
     float sys_dt = 0.f;
     double sys_s2 = 1.0;            // dx^2 scaling of the divergence system
     bool sys_coupled = false;
@@ -367,6 +376,20 @@ __device__ __forceinline__ double d_block_sum(double v, double *scratch) {
     if (lane == 0) scratch[wave] = v;
     __syncthreads();
     return ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+}
+// d_block_sum of s and d_block_max of m behind one pair of barriers (scratch: 8 doubles)
+__device__ __forceinline__ void d_block_sum_max(double &s, double &m, double *scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, FLIP_WAVE);
+        m = fmax(m, __shfl_down(m, off, FLIP_WAVE));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { scratch[wave] = s; scratch[4 + wave] = m; }
+    __syncthreads();
+    s = ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+    m = fmax(fmax(scratch[4], scratch[5]), fmax(scratch[6], scratch[7]));
 }
 __device__ __forceinline__ double d_block_max(double v, double *scratch) {
 #pragma unroll

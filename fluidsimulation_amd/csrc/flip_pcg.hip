@@ -289,6 +289,12 @@ extern "C" int flip_set_system_options(flip_ctx *ctx, int drop_null_rows, int el
     return 0;
 }
 
+extern "C" int flip_set_warm_start(flip_ctx *ctx, int enabled) {
+    FLIP_REQUIRE(ctx, "null context");
+    ctx->warm_start = enabled != 0;
+    return 0;
+}
+
 extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     FLIP_REQUIRE(ctx, "null context");
     FLIP_REQUIRE(kind == FLIP_SOLVE_DIVERGENCE || kind == FLIP_SOLVE_DENSITY, "flip_build_system: unknown kind");
@@ -479,6 +485,36 @@ __device__ __forceinline__ double d_reduce_partials(const double *__restrict__ p
     return d_block_sum(v, scratch);
 }
 
+// |r|^2, r.z (slots 0 and 1, summed exactly as d_reduce_partials does) and, if asked, max|r| (slot 11) behind one pair of
+// barriers.  scratch: 12 doubles.
+__device__ __forceinline__ void d_reduce_rr_rz_rinf(const double *__restrict__ partial, int nblk, bool with_max, double *scratch, double &rr,
+                                                    double &rz, double &rinf) {
+    double a = 0.0, b = 0.0, m = 0.0;
+    for (int q = threadIdx.x; q < nblk; q += FLIP_BLOCK) {
+        a += partial[0 * FLIP_MAX_PCG_BLOCKS + q];
+        b += partial[1 * FLIP_MAX_PCG_BLOCKS + q];
+        if (with_max) m = fmax(m, partial[11 * FLIP_MAX_PCG_BLOCKS + q]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, FLIP_WAVE);
+        b += __shfl_down(b, off, FLIP_WAVE);
+        m = fmax(m, __shfl_down(m, off, FLIP_WAVE));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { scratch[wave] = a; scratch[4 + wave] = b; scratch[8 + wave] = m; }
+    __syncthreads();
+    rr = ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+    rz = ((scratch[4] + scratch[5]) + scratch[6]) + scratch[7];
+    rinf = fmax(fmax(scratch[8], scratch[9]), fmax(scratch[10], scratch[11]));
+}
+__device__ __forceinline__ double d_block_max_of(const double *__restrict__ part, int nblk, double *scratch) {
+    double v = 0.0;
+    for (int q = threadIdx.x; q < nblk; q += FLIP_BLOCK) v = fmax(v, part[q]);
+    return d_block_max(v, scratch);
+}
+
 // Row c of A applied to the vector whose entry at cell q is get(q).
 template <class Get>
 __device__ __forceinline__ double d_apply_row(const PcgArgs &A, long long c, uint8_t fl, double pc, Get get) {
@@ -503,26 +539,55 @@ __device__ __forceinline__ void d_row_range(const PcgArgs &A, long long &lo, lon
 }
 
 // x, z, p0, p1 are zeroed by the host before this kernel (cells off the CG rows must read as zero).
+// WARM: x holds a guess (zero off the CG rows, k_warm_mask), so r = b - A x with the symmetric CG couplings, and |b|^2
+// goes to partial slot 9 because |r_0|^2 no longer is the norm the stopping rule refers to.
+template <bool WARM>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_init(PcgArgs A) {
-    __shared__ double scratch[4];
+    __shared__ double scratch[8];
     long long lo, hi;
     d_row_range(A, lo, hi);
-    double rr = 0.0, rz = 0.0;
+    double rr = 0.0, rz = 0.0, bb = 0.0, binf = 0.0, rinf = 0.0;
+    const long long sy = A.sy, sz = A.sz;
+    const double *__restrict__ x = A.x;
     for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
         const long long c = A.rows[q];
-        const double r = A.rhs[c];
+        double r = A.rhs[c];
+        binf = fmax(binf, fabs(r));
+        if (WARM) {
+            bb += r * r;
+            double acc = (double)A.cgx[c] * x[c - 1];
+            acc += (double)A.cgx[c + 1] * x[c + 1];
+            acc += (double)A.cgy[c] * x[c - sy];
+            acc += (double)A.cgy[c + sy] * x[c + sy];
+            acc += (double)A.cgz[c] * x[c - sz];
+            acc += (double)A.cgz[c + sz] * x[c + sz];
+            r -= A.cg_diag[c] * x[c] - A.s2 * acc;
+        }
         const double z = A.cg_inv[c] * r;
         rr += r * r;
         rz += r * z;
+        rinf = fmax(rinf, fabs(r));
         A.r[c] = r;
         A.z[c] = z;
     }
-    rr = d_block_sum(rr, scratch);
-    rz = d_block_sum(rz, scratch);
+    d_block_sum_max(rr, binf, scratch);
+    d_block_sum_max(rz, rinf, scratch);
+    if (WARM) bb = d_block_sum(bb, scratch);
     if (threadIdx.x == 0) {
         A.partial[0 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rr;
         A.partial[1 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rz;
+        if (WARM) A.partial[9 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = bb;
+        A.partial[10 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = binf;
+        A.partial[11 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rinf;
     }
+}
+// the guess of a warm start must be zero wherever the new system has no CG row (the stencil reads x at neighbours)
+__global__ void k_warm_mask(long long B, const double *__restrict__ cg_inv, double *__restrict__ x) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    const double v = x[c];
+    // also drops anything non-finite a diverged earlier solve may have left
+    if (cg_inv[c] == 0.0 || !(fabs(v) <= DBL_MAX)) x[c] = 0.0;
 }
 
 // SYM = true: the CG rows couple symmetrically (dependent rows eliminated), so the coefficient toward the
@@ -531,25 +596,41 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_init(PcgArgs A) {
 // SYM = false: CG over all rows of the non-symmetric matrix as the reference runs it (flag-driven).
 template <bool SYM>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_direction(PcgArgs A) {
-    __shared__ double scratch[4];
+    __shared__ double scratch[12];
     flip_pcg_scalars *S = A.scal;
     if (S->done) return;
     const int it = S->it_a;
-    const double rr = d_reduce_partials(A.partial + 0 * FLIP_MAX_PCG_BLOCKS, A.nblk, scratch);
-    const double rz = d_reduce_partials(A.partial + 1 * FLIP_MAX_PCG_BLOCKS, A.nblk, scratch);
+    double rr, rz, rinf;
+    d_reduce_rr_rz_rinf(A.partial, A.nblk, S->track_inf != 0, scratch, rr, rz, rinf);
+    if (S->track_inf) {
+        const double binf = it == 0 ? d_block_max_of(A.partial + 10 * FLIP_MAX_PCG_BLOCKS, A.nblk, scratch) : S->binf;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (it == 0) S->binf = binf;
+            S->rinf = rinf;
+            if (S->it_inf < 0 && rinf <= 1e-12 * binf) S->it_inf = it;
+        }
+    }
     double beta = 0.0;
     if (it == 0) {
         // Eigen: rhsNorm2 == 0 -> x = 0; threshold = max(tol^2 |b|^2, DBL_MIN)
-        double thr = S->tol2 * rr;
+        const double bb = S->warm ? d_reduce_partials(A.partial + 9 * FLIP_MAX_PCG_BLOCKS, A.nblk, scratch) : rr;
+        double thr = S->tol2 * bb;
         if (thr < DBL_MIN) thr = DBL_MIN;
-        const bool stop = rr == 0.0 || rr < thr;
+        const bool stop = bb == 0.0 || rr < thr;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            S->rhs_norm2 = rr;
+            S->rhs_norm2 = bb;
             S->threshold = thr;
             S->rr = rr;
             if (stop) S->done = 1;
         }
-        if (stop) return;
+        if (stop) {
+            if (S->warm && bb == 0.0) {   // the answer to a zero right-hand side is zero, not the guess
+                long long lo, hi;
+                d_row_range(A, lo, hi);
+                for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) A.x[A.rows[q]] = 0.0;
+            }
+            return;
+        }
     } else {
         const bool conv = rr < S->threshold;
         const bool stop = conv || it >= S->max_iter;
@@ -631,7 +712,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_direction(PcgArgs A) {
 }
 
 __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update(PcgArgs A) {
-    __shared__ double scratch[4];
+    __shared__ double scratch[8];
     flip_pcg_scalars *S = A.scal;
     if (S->done) return;
     const int it = S->it_b;
@@ -650,7 +731,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update(PcgArgs A) {
     const double *__restrict__ p = (it & 1) ? A.p1 : A.p0;
     long long lo, hi;
     d_row_range(A, lo, hi);
-    double rr = 0.0, rz = 0.0;
+    double rr = 0.0, rz = 0.0, rinf = 0.0;
     const double *__restrict__ inv = A.cg_inv;
 #pragma unroll 2
     for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
@@ -670,12 +751,14 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update(PcgArgs A) {
         A.z[c] = zz;
         rr += r * r;
         rz += r * zz;
+        rinf = fmax(rinf, fabs(r));
     }
-    rr = d_block_sum(rr, scratch);
+    d_block_sum_max(rr, rinf, scratch);
     rz = d_block_sum(rz, scratch);
     if (threadIdx.x == 0) {
         A.partial[0 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rr;
         A.partial[1 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rz;
+        A.partial[11 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rinf;
         if (blockIdx.x == 0) S->it_a = it + 1;
     }
 }
@@ -690,7 +773,7 @@ struct FusedArgs {
     double *r2;
 };
 __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update_pre(PcgArgs A, FusedArgs F) {
-    __shared__ double scratch[4];
+    __shared__ double scratch[8];
     flip_pcg_scalars *S = A.scal;
     if (S->done) return;
     const int it = S->it_b;
@@ -705,7 +788,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update_pre(PcgArgs A, FusedA
     const long long sy = A.sy, sz = A.sz;
     long long lo, hi;
     d_row_range(A, lo, hi);
-    double rr = 0.0;
+    double rr = 0.0, rinf = 0.0;
     const float creg = S->creg;
 #pragma unroll 2
     for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
@@ -729,10 +812,12 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update_pre(PcgArgs A, FusedA
         A.x[c] = A.x[c] + alpha * p[c];
         rn[c] = rc;
         rr += rc * rc;
+        rinf = fmax(rinf, fabs(rc));
     }
-    rr = d_block_sum(rr, scratch);
+    d_block_sum_max(rr, rinf, scratch);
     if (threadIdx.x == 0) {
         A.partial[0 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rr;
+        A.partial[11 * FLIP_MAX_PCG_BLOCKS + blockIdx.x] = rinf;
         if (blockIdx.x == 0) S->it_a = it + 1;
     }
 }
@@ -811,7 +896,15 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
     if (max_iter <= 0) max_iter = 2 * (ctx->n_rows > 0 ? ctx->n_rows : 1);
 
     // cells off the CG rows must read as zero in x and in the vectors the stencil reads at neighbours
-    FLIP_CHECK(hipMemsetAsync(ctx->x, 0, (size_t)ctx->B * 8, st));
+    // Warm start: the last converged solution of a system of the same kind on these arrays is the guess (Eigen's
+    // solveWithGuess; the stopping rule is the same |r| < tol |b|, so the result meets the same bound).  Only for the
+    // plain symmetric system: the rigid-body term and the as-run non-symmetric form start from zero as the reference does.
+    const bool warm = ctx->warm_start && ctx->x_kind == ctx->sys_kind && ctx->sys_eliminated && !ctx->sys_coupled;
+    ctx->x_kind = -1;
+    if (warm) {
+        k_warm_mask<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, ctx->cg_inv, ctx->x);
+        FLIP_LAUNCH_CHECK();
+    } else FLIP_CHECK(hipMemsetAsync(ctx->x, 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->z, 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->pv[0], 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->pv[1], 0, (size_t)ctx->B * 8, st));
@@ -832,6 +925,9 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
     h.max_iter = max_iter;
     h.fused = fused ? 1 : 0;
     h.creg = ctx->reg_value;
+    h.warm = warm ? 1 : 0;
+    h.track_inf = 1;
+    h.it_inf = -1;
     k_set_scalars<<<1, 1, 0, st>>>(ctx->scal, h); // by value: no host buffer has to outlive the call
     FLIP_LAUNCH_CHECK();
     PcgArgs A;
@@ -842,7 +938,8 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
         ctx->events.push_back(e);
     }
     FLIP_CHECK(hipEventRecord(ctx->events[0], st));
-    k_pcg_init<<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(A);
+    if (warm) k_pcg_init<true><<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(A);
+    else k_pcg_init<false><<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(A);
     FLIP_LAUNCH_CHECK();
     if (use_mg)
         if (int rc = flip_mg_vcycle(ctx)) return rc;
@@ -975,6 +1072,7 @@ static int pcg_enqueue_tail(flip_ctx *ctx, PcgTail &t) {
 static int pcg_report(flip_ctx *ctx, const PcgRun &run, const PcgTail &t, flip_pcg_info *info) {
     ctx->n_active_chunks = t.counts[1];
     if (run.use_mg && t.h.done == 1) ctx->last_iterations[ctx->sys_kind & 1] = t.h.it_a;
+    ctx->x_kind = t.h.done == 1 ? ctx->sys_kind : -1;
     if (!info) return 0;
     memset(info, 0, sizeof *info);
     info->converged = t.h.done == 1 ? 1 : 0;
@@ -985,6 +1083,8 @@ static int pcg_report(flip_ctx *ctx, const PcgRun &run, const PcgTail &t, flip_p
     info->cg_rows = t.counts[6];
     info->rhs_norm_2 = sqrt(t.h.rhs_norm2);
     info->rel_residual_2 = t.h.rhs_norm2 > 0 ? sqrt(t.h.rr / t.h.rhs_norm2) : 0.0;
+    info->iterations_inf = t.h.track_inf ? t.h.it_inf : -1;
+    info->rel_residual_inf = (t.h.track_inf && t.h.binf > 0) ? t.h.rinf / t.h.binf : 0.0;
     float ms = 0.f;
     FLIP_CHECK(hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]));
     info->seconds = (double)ms * 1e-3;
@@ -1296,6 +1396,7 @@ extern "C" int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, 
     h.creg = ctx->reg_value;
     k_set_scalars<<<1, 1, 0, st>>>(ctx->scal, h); // by value: no host buffer has to outlive the call
     FLIP_LAUNCH_CHECK();
+    ctx->x_kind = -1; // the slab solve starts from zero
     FLIP_CHECK(hipMemsetAsync(ctx->x, 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->z, 0, (size_t)ctx->B * 8, st));
     FLIP_CHECK(hipMemsetAsync(ctx->r, 0, (size_t)ctx->B * 8, st));
@@ -1320,7 +1421,7 @@ extern "C" int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, 
         ctx->events.push_back(e);
     }
     FLIP_CHECK(hipEventRecord(ctx->events[0], st));
-    k_pcg_init<<<nblk, FLIP_BLOCK, 0, st>>>(A);
+    k_pcg_init<false><<<nblk, FLIP_BLOCK, 0, st>>>(A);
     FLIP_LAUNCH_CHECK();
     if (ctx->slab_overlap > 0) return 0; // the caller continues with the residual exchange, precondition() and combine()
     if (use_mg)
@@ -1460,6 +1561,7 @@ extern "C" int flip_pcg_dist_finish(flip_ctx *ctx, flip_pcg_info *info) {
         info->cg_rows = counts[6];
         info->rhs_norm_2 = sqrt(h.rhs_norm2);
         info->rel_residual_2 = h.rhs_norm2 > 0 ? sqrt(h.rr / h.rhs_norm2) : 0.0;
+        info->iterations_inf = -1; // a maximum over the slabs is not exchanged
         float ms = 0.f;
         FLIP_CHECK(hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]));
         info->seconds = (double)ms * 1e-3;

@@ -109,7 +109,9 @@ typedef struct flip_pcg_info {
     double spmv_seconds;    /* device time spent in the operator kernel, when profiled     */
     int32_t spmv_launches;  /* launches covered by spmv_seconds                            */
     int32_t dependent_rows; /* rows solved by substitution after CG (see flip_set_system_options) */
-    int32_t reserved;
+    int32_t iterations_inf; /* iterations after which max|r| <= 1e-12 max|b| first held, the stopping rule of  */
+                            /* headers/pcgsolver/pcg_solver.h:241-258 (-1: never, or not tracked: slab solves) */
+    double rel_residual_inf; /* max|r| / max|b| when the solve stopped                                         */
 } flip_pcg_info;
 
 /* ---- context ---------------------------------------------------------------------------- */
@@ -262,6 +264,14 @@ int flip_build_system(flip_ctx *ctx, int kind, float dt);
  *     the whole non-symmetric matrix as the reference does.  With a rigid body whose coupling rows touch a
  *     dependent row the library solves the whole system regardless. */
 int flip_set_system_options(flip_ctx *ctx, int drop_null_rows, int eliminate_dependent_rows);
+/* Warm start of the solves (default 0: x0 = 0, as the reference's Eigen solve() starts, src/FluidSimulator.cpp:823,
+ * :1007).  With 1 a solve starts from the converged solution of the previous system of the same kind on this context
+ * instead (Eigen's solveWithGuess), masked to the rows of the new system.  The stopping rule |r| < tol |b| is the same,
+ * so the result meets the same bound; only the iteration count changes -- and at the reference's tolerance of 1e-15 it
+ * hardly does (50.6 against 50.75 iterations per substep on the 256^3 dam break: the rows that change at the free
+ * surface leave a first residual of the order of |b|), which is why it is off.  Applies to the symmetric system
+ * without a rigid body; every other solve starts from zero whatever this says. */
+int flip_set_warm_start(flip_ctx *ctx, int enabled);
 /* Parity hook: the assembled stencil on the box: off[6][B] (faces -x,+x,-y,+y,-z,+z), diag[B],
  * rhs[B]; zero off the rows.  Any pointer may be NULL. */
 int flip_system_download(flip_ctx *ctx, double *off, double *diag, double *rhs);

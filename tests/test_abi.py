@@ -57,9 +57,25 @@ def test_field_enum_matches_header():
 
 def test_struct_sizes_match_the_c_layout():
     assert ctypes.sizeof(binding.GridDesc) == 6 * 4 + 4 * 4
-    # 5 ints (+4 pad), 4 doubles, 3 ints (+4 pad)
-    assert ctypes.sizeof(binding.PcgInfo) == 24 + 32 + 16
+    # 5 ints (+4 pad), 4 doubles, 3 ints (+4 pad), 1 double
+    assert ctypes.sizeof(binding.PcgInfo) == 24 + 32 + 16 + 8
     assert binding.PcgInfo.rel_residual_2.offset == 24 and binding.PcgInfo.spmv_launches.offset == 56
+    assert binding.PcgInfo.iterations_inf.offset == 64 and binding.PcgInfo.rel_residual_inf.offset == 72
+
+
+def test_pcg_info_layout_is_what_the_c_compiler_gives(tmp_path):
+    """sizeof / offsetof of flip_pcg_info as gcc lays the header's struct out, against the ctypes mirror."""
+    import subprocess
+    src = tmp_path / "layout.c"
+    fields = [name for name, _ in binding.PcgInfo._fields_]
+    body = "".join(f'printf("%zu\\n", offsetof(flip_pcg_info, {f}));' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "flip_hip.h"\nint main(void){printf("%zu\\n", sizeof(flip_pcg_info));'
+                   + body + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.dirname(HEADER), "-o", str(exe), str(src)], check=True)
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(binding.PcgInfo)
+    assert out[1:] == [getattr(binding.PcgInfo, f).offset for f in fields]
 
 
 def test_create_fails_loudly_without_a_device():

@@ -1084,3 +1084,76 @@ def test_buffer_swaps_exchange_front_and_back():
         for a, n in enumerate("uvw"):
             assert np.array_equal(ctx.download(f"vel_{n}"), back[a]) and np.array_equal(ctx.download(f"vel_back_{n}"), front[a])
             assert np.array_equal(ctx.download(f"valid_{n}"), vb[a]) and np.array_equal(ctx.download(f"valid_back_{n}"), vf[a])
+
+
+def test_warm_start_reaches_the_same_pressure_in_fewer_iterations():
+    """flip_set_warm_start: a solve that starts from the previous substep's converged solution (Eigen's solveWithGuess
+    instead of the reference's solve(), src/FluidSimulator.cpp:823, :1007) stops by the same rule |r| < tol |b|, so it
+    must give the same pressure to solver accuracy; the first substep has no previous solution and is identical."""
+    from fluidsimulation_amd import FlipSubstep, PRECOND_MULTIGRID, SOLVE_DENSITY
+    sc = scenes.dam_break_slab(64, ppc=8, seed=12345)
+    radius = 1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0
+    runs = {}
+    for warm in (False, True):
+        with FlipContext(sc.desc()) as ctx:
+            ctx.upload_scene(sc)
+            ctx.set_warm_start(warm)
+            step = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, concurrent_solves=True, constrain=True, advect=True, levelset_radius=radius)
+            infos = [step.step(0.002) for _ in range(6)]
+            p_div = ctx.download("pressure")
+            ctx.select_system(SOLVE_DENSITY)
+            p_den = ctx.download("pressure")
+            pos, vel = ctx.download_particles()
+            runs[warm] = (infos, p_div, p_den, pos, vel)
+    cold, hot = runs[False], runs[True]
+    for infos in (cold[0], hot[0]):
+        for info in infos:
+            for k in ("divergence", "density"):
+                assert info[k]["converged"] == 1 and info[k]["rel_residual_2"] < RES_TOL, info[k]
+    for k in ("divergence", "density"):
+        assert hot[0][0][k]["iterations"] == cold[0][0][k]["iterations"]
+        assert hot[0][0][k]["rhs_norm_2"] == cold[0][0][k]["rhs_norm_2"]
+    its = lambda infos: sum(i[k]["iterations"] for i in infos[1:] for k in ("divergence", "density"))
+    assert its(hot[0]) < its(cold[0]), (its(hot[0]), its(cold[0]))
+    # |b| of the later substeps is the norm of the right-hand side, not of the first residual
+    for a, b in zip(cold[0][1:], hot[0][1:]):
+        for k in ("divergence", "density"):
+            assert abs(a[k]["rhs_norm_2"] - b[k]["rhs_norm_2"]) <= 1e-6 * a[k]["rhs_norm_2"], (a[k], b[k])
+    assert rel_linf(hot[1], cold[1]) < 1e-8 and rel_linf(hot[2], cold[2]) < 1e-8
+    assert np.abs(hot[3] - cold[3]).max() < POS_ATOL and rel_linf(hot[4], cold[4]) < VEL_RTOL
+
+
+@pytest.mark.parametrize("precond", [0, 1])
+def test_the_pcgsolver_stopping_rule_is_reported(precond):
+    """flip_pcg_info::iterations_inf / rel_residual_inf watch the rule of headers/pcgsolver/pcg_solver.h:241-258
+    (max|r| <= 1e-12 max|b|) beside Eigen's: a solve capped at the reported count satisfies the rule, one capped an
+    iteration earlier does not, and the reported ratio is that of the true residual b - A x of the downloaded system."""
+    from fluidsimulation_amd import SOLVE_DIVERGENCE
+    sc = scenes.dam_break(32, ppc=4, seed=6)
+    rng = np.random.default_rng(21)
+    sc.vel = rng.normal(0, 0.3, sc.pos.shape)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        ctx.bin_particles()
+        ctx.p2g()
+        ctx.add_forces(0.005)
+        ctx.index_cells()
+        ctx.face_fractions()
+        ctx.build_system(SOLVE_DIVERGENCE, 0.005)
+        full = ctx.pcg_solve(1e-15, 0, precond)
+        k = full["iterations_inf"]
+        assert full["converged"] == 1 and 0 < k <= full["iterations"], full
+        assert full["rel_residual_inf"] <= 1e-12
+        at = ctx.pcg_solve(1e-15, k, precond)
+        assert at["iterations"] == k and at["iterations_inf"] == k and at["rel_residual_inf"] <= 1e-12, at
+        off, diag, rhs = ctx.download_system()
+        x = ctx.download("pressure")
+        xp = np.pad(x, 1)
+        ax = diag * x
+        ax += off[0] * xp[1:-1, 1:-1, :-2] + off[1] * xp[1:-1, 1:-1, 2:]
+        ax += off[2] * xp[1:-1, :-2, 1:-1] + off[3] * xp[1:-1, 2:, 1:-1]
+        ax += off[4] * xp[:-2, 1:-1, 1:-1] + off[5] * xp[2:, 1:-1, 1:-1]
+        true_ratio = np.abs(rhs - ax).max() / np.abs(rhs).max()
+        assert true_ratio <= 1.5e-12 and abs(true_ratio - at["rel_residual_inf"]) <= 0.05 * at["rel_residual_inf"] + 1e-15, (true_ratio, at)
+        before = ctx.pcg_solve(1e-15, k - 1, precond)
+        assert before["iterations"] == k - 1 and before["iterations_inf"] == -1 and before["rel_residual_inf"] > 1e-12, before
