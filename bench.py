@@ -247,15 +247,16 @@ def kernel_source_id():
 def stored_traffic(args):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this command (FETCH_SIZE and WRITE_SIZE need
     passes of their own, so they cannot be read live): profiles/traffic.json, written by profiles/summarize_pmc.py, holds
-    {kernel: bytes} plus the source hash and the configuration it was taken on.  Returns ({}, None) when absent or taken
-    on other code or another configuration."""
+    {kernel: bytes} plus the source hash and the configuration it was taken on, --steps and --warmup included (the scene
+    state the counters saw).  Returns ({}, None) when absent or taken on other code or another configuration."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
         return {}, None
     with open(path) as f:
         d = json.load(f)
     if (d.get("source_id") != kernel_source_id() or d.get("n") != args.n or d.get("ppc") != args.ppc
-            or d.get("hot_path_only", False) != args.hot_path_only or d.get("dt") != args.dt):
+            or d.get("hot_path_only", False) != args.hot_path_only or d.get("dt") != args.dt
+            or d.get("steps") != args.steps or d.get("warmup") != args.warmup):
         return {}, None
     return d.get("bytes_per_launch", {}), d.get("files")
 
@@ -455,20 +456,8 @@ def main():
                 stages["coarse_levels"] = stage_entry(t_c, its_per_step, rows * 34, "all launches of the V-cycle below level 0 of one "
                                                       "iteration, run alone (bound by launch and dependent-load latency; beside the other "
                                                       "solve's level-0 kernels they mostly hide)")
-        # particle-side kernels and stages, timed alone on the state the run has reached
-        ctx.bin_particles(want_outside=False)
-        if not args.hot_path_only:
-            t_ls = time_stage(torch, lambda: ctx.fluid_levelset_from_particles(radius))
-            stages["fluid_levelset"] = stage_entry(t_ls, 1, LEVELSET_BYTES_PER_PARTICLE * n_local + LEVELSET_BYTES_PER_CELL * sc.n_cells,
-                                                   "whole stage: occupancy dilation, shells 0-1 for every cell, compaction, full search of the rest")
-        t_p2g = time_stage(torch, ctx.p2g)
-        band = int(ctx.download("active").astype(np.int64).sum())
-        ctx.update_diff()
-        t_g2p = time_stage(torch, lambda: ctx.g2p(0.95))
-        entries.append(roofline_entry("k_gather", t_p2g, 1, P2G_BYTES_PER_PARTICLE * n_local + P2G_BYTES_PER_BAND_CELL * band, traffic,
-                                      note="flip_p2g = this one kernel (k_gather<true, 2>): P2G and, in the same walk, the density field"))
-        entries.append(roofline_entry("k_g2p", t_g2p, 1, G2P_BYTES_PER_PARTICLE * n_local + G2P_BYTES_PER_BAND_CELL * band, traffic))
-        # binning as the substep meets it: right after a whole substep (which ends with moved particles, the sort stale)
+        # binning as the substep meets it: right after a whole substep (which ends with moved particles, the sort stale);
+        # measured first, on the state the run has reached, before anything below touches the particles
         t_bin = 0.0
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
@@ -480,7 +469,23 @@ def main():
             e1.synchronize()
             t_bin += e0.elapsed_time(e1) * 1e-3 / 3
         stages["binning"] = stage_entry(t_bin, 1, SORT_BYTES_PER_PARTICLE * n_local, "whole stage after a real substep: cell ids, scan, slots, "
-                                        "per-row reorder (stable order + half-cell ordered copy), bands, gather tile list")
+                                        "per-row reorder (stable order + half-cell ordered copy), bands, gather work list")
+        # particle-side kernels and stages, timed alone on that state; the repeated G2P calls change the particle
+        # velocities, so the particles are put back afterwards
+        saved = ctx.download_particles() + (ctx.download_mass(),)
+        if not args.hot_path_only:
+            t_ls = time_stage(torch, lambda: ctx.fluid_levelset_from_particles(radius))
+            stages["fluid_levelset"] = stage_entry(t_ls, 1, LEVELSET_BYTES_PER_PARTICLE * n_local + LEVELSET_BYTES_PER_CELL * sc.n_cells,
+                                                   "whole stage: occupancy dilation, shells 0-1 for every cell, compaction, full search of the rest")
+        t_p2g = time_stage(torch, ctx.p2g)
+        band = int(ctx.download("active").astype(np.int64).sum())
+        ctx.update_diff()
+        t_g2p = time_stage(torch, lambda: ctx.g2p(0.95))
+        entries.append(roofline_entry("k_gather", t_p2g, 1, P2G_BYTES_PER_PARTICLE * n_local + P2G_BYTES_PER_BAND_CELL * band, traffic,
+                                      note="flip_p2g = k_gather<true, 2, 2, 2> (P2G and, in the same walk, the density field) after k_gather_clear "
+                                           "(zeros outside the band, ~4 % of the time)"))
+        entries.append(roofline_entry("k_g2p", t_g2p, 1, G2P_BYTES_PER_PARTICLE * n_local + G2P_BYTES_PER_BAND_CELL * band, traffic))
+        ctx.upload_particles(*saved)
         if world == 1 and not args.no_cpu_baseline and not slabs:
             # iteration counts of the reference's own solver (Jacobi CG) on this scene, for the CPU extrapolation
             probe = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=PRECOND_JACOBI).step(args.dt)

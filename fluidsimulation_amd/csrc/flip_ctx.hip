@@ -157,7 +157,7 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
     dfree(c->dist_sums); dfree(c->mg_rows); dfree(c->dist_recv[0]); dfree(c->dist_recv[1]);
     if (c->dist_rw) (void)hipFree(c->dist_rw - c->pad);
     dfree(c->d_vmax);
-    dfree(c->gather_stats); dfree(c->tile_scan); dfree(c->tile_list);
+    dfree(c->gather_stats); dfree(c->tile_scan); dfree(c->tile_list); dfree(c->slot_scan); dfree(c->slot_list); dfree(c->gather_claim);
     delete c;
 }
 
@@ -206,6 +206,7 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     A(c->gather_stats, 4)
     c->n_tiles = (int64_t)((desc->nx + 3) / 4) * ((desc->ny + 3) / 4) * ((desc->nz + 3) / 4);
     A(c->tile_scan, c->n_tiles + 1) A(c->tile_list, c->n_tiles)
+    A(c->slot_scan, B + 1) A(c->slot_list, B) A(c->gather_claim, 8)
 #undef A
     if (e != hipSuccess) {
         flip_ctx_destroy(c);
@@ -392,7 +393,7 @@ extern "C" int flip_particles_reserve(flip_ctx *ctx, int64_t capacity) {
 
 extern "C" int flip_particles_upload(flip_ctx *ctx, int64_t n, const double *pos, const double *vel, const float *mass) {
     FLIP_REQUIRE(ctx, "null context");
-    FLIP_REQUIRE(n >= 0 && n < (int64_t)2000000000, "flip_particles_upload: particle count out of range");
+    FLIP_REQUIRE(n >= 0 && n < ((int64_t)1 << 30), "flip_particles_upload: particle count out of range (fewer than 2^30 per context)");
     FLIP_REQUIRE(n == 0 || (pos && vel && mass), "flip_particles_upload: null array");
     FLIP_CHECK(hipSetDevice(ctx->device));
     if (int rc = ensure_particle_capacity(ctx, n)) return rc;

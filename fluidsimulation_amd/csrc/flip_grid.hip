@@ -371,9 +371,10 @@ extern "C" int flip_velocity_max(flip_ctx *ctx, double out_max[3]) {
     return 0;
 }
 
-// The same reduction for callers that must not allocate (code under HIP graph capture, serving loops, harnesses that
-// forbid hipMalloc): the per-workgroup partial maxima live in a file-scope device array instead of memory the library
-// allocated, and the host side uses no container.  The array's name is only a host-side handle: its device address is
+// The same reduction for callers that must not allocate (tight serving loops, harnesses that forbid hipMalloc): the
+// per-workgroup partial maxima live in a file-scope device array instead of memory the library allocated, and the host
+// side uses no container.  It is not a call for a stream under graph capture: the result goes back with a copy into the
+// caller's (pageable) host memory and a stream synchronise, neither of which a capture allows.  The array's name is only a host-side handle: its device address is
 // looked up once per device with hipGetSymbolAddress and kept; every GPU holds its own copy at its own address.
 #define FLIP_STATIC_VMAX_BLOCKS 4096          // workgroups at most
 #define FLIP_STATIC_VMAX_CELLS_PER_BLOCK 16384 // 256 threads x 64 cells
@@ -427,6 +428,7 @@ extern "C" int flip_velocity_max_static(flip_ctx *ctx, double out_max[3]) {
     }
     const int nblk = (int)((ctx->B + FLIP_STATIC_VMAX_CELLS_PER_BLOCK - 1) / FLIP_STATIC_VMAX_CELLS_PER_BLOCK);
     k_vel_max_static<<<nblk, FLIP_BLOCK, 0, ctx->stream>>>(ctx->B, ctx->active, ctx->vel[0][0], ctx->vel[0][1], ctx->vel[0][2], part);
+    FLIP_LAUNCH_CHECK();
     k_vel_max_static_final<<<1, FLIP_BLOCK, 0, ctx->stream>>>(nblk, part);
     FLIP_LAUNCH_CHECK();
     FLIP_CHECK(hipMemcpyAsync(out_max, part + 3 * FLIP_STATIC_VMAX_BLOCKS, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

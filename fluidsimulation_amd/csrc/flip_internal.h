@@ -135,6 +135,10 @@ struct flip_ctx {
     int32_t *sub_slot = nullptr;    // [cap] place of primary slot s in the half-cell order
     int64_t n_tiles = 0;            // 4 x 4 x 4-cell tiles of the box (the LDS-staged gather's work units)
     int32_t *tile_scan = nullptr;   // [n_tiles + 1] flags, then their exclusive scan; [n_tiles] = tiles that hold a band cell
+    int32_t *slot_scan = nullptr;   // [B + 1] flags of the per-lane gather's slots, then their exclusive scan; [slots] = listed slots
+    int32_t *slot_list = nullptr;   // [B] the slots that hold a cell of the band (k_gather_slot_flags)
+    int32_t *gather_claim = nullptr; // [8] claim counters of k_gather, one per part of the list
+    int slot_list_shape = 0;        // what the lists hold: cells per slot as ry * 16 + rz, -1 = the tile list, 0 = nothing
     int32_t *tile_list = nullptr;   // [n_tiles] those tiles, ascending
     int n_cu = 256;                 // compute units of the device
     int gather_mode = 0;            // 0: k_gather (per-lane walk of global memory), 1: k_gather_tile (LDS-staged)

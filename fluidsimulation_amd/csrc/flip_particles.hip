@@ -282,6 +282,8 @@ __global__ void k_band_axis(GridDims g, int axis, const uint8_t *__restrict__ in
 }
 
 #define GT_T 4 // edge of the LDS-staged gather's tiles in cells (see k_gather_tile)
+static int gather_column();
+static int gather_planes();
 // tiles with a cell of the band (bit 1): flag, then compacted by a scan into the list the gather's workgroups share out
 __global__ void k_gather_tile_flags(GridDims g, int tiles_x, int tiles_y, long long ntiles, const uint8_t *__restrict__ band,
                                     int32_t *__restrict__ flag) {
@@ -299,10 +301,54 @@ __global__ void k_gather_tile_flags(GridDims g, int tiles_x, int tiles_y, long l
         }
     flag[t] = any ? 1 : 0;
 }
+// Work list of the per-lane gather: a slot is a column of ry cells in each of rz planes (the cells of one thread of
+// k_gather); it is listed iff one of its cells lies in the band.  The gather's lanes take consecutive list entries, so
+// that a wave holds 64 slots with work whatever the shape of the liquid (slot numbering = x fastest, as the cells).
+__global__ void k_gather_slot_flags(GridDims g, int ry, int rz, int nyb, long long nslots, const uint8_t *__restrict__ band,
+                                    int32_t *__restrict__ scan) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > nslots) return;
+    if (t == nslots) { scan[t] = 0; return; }
+    const int i = (int)(t % g.nx);
+    const long long tq = t / g.nx;
+    const int j0 = (int)(tq % nyb) * ry, k0 = (int)(tq / nyb) * rz;
+    int flag = 0;
+    for (int dk = 0; dk < rz; ++dk)
+        for (int dj = 0; dj < ry; ++dj)
+            if (j0 + dj < g.ny && k0 + dk < g.nz && (band[d_lid(g, i, j0 + dj, k0 + dk)] & 2)) flag = 1;
+    scan[t] = flag;
+}
 __global__ void k_gather_tile_list(long long ntiles, const int32_t *__restrict__ scan, int32_t *__restrict__ list) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     if (scan[t + 1] > scan[t]) list[scan[t]] = (int32_t)t;
+}
+
+// The work list of the form of the gather the context uses (after the band passes of the binning, or when the form
+// was switched since): list_shape says which one the arrays hold.
+static int build_gather_lists(flip_ctx *ctx) {
+    const GridDims g = flip_dims(ctx);
+    hipStream_t st = ctx->stream;
+    if (ctx->gather_mode != 1) {   // the slots of the per-lane gather that hold a cell of the band
+        const int ry = gather_column(), rz = gather_planes();
+        const int nyb = (ctx->g.ny + ry - 1) / ry, nzb = (ctx->g.nz + rz - 1) / rz;
+        const long long nslots = (long long)ctx->g.nx * nyb * nzb;
+        k_gather_slot_flags<<<flip_grid_blocks(nslots + 1), FLIP_BLOCK, 0, st>>>(g, ry, rz, nyb, nslots, ctx->band, ctx->slot_scan);
+        FLIP_LAUNCH_CHECK();
+        if (int rc = flip_exclusive_scan(ctx, ctx->slot_scan, nslots + 1)) return rc;
+        k_gather_tile_list<<<flip_grid_blocks(nslots), FLIP_BLOCK, 0, st>>>(nslots, ctx->slot_scan, ctx->slot_list);
+        FLIP_LAUNCH_CHECK();
+        ctx->slot_list_shape = ry * 16 + rz;
+    } else {   // the tiles of the LDS-staged gather that hold a cell of the band
+        ctx->slot_list_shape = -1;
+        const int tx = (ctx->g.nx + GT_T - 1) / GT_T, ty = (ctx->g.ny + GT_T - 1) / GT_T;
+        k_gather_tile_flags<<<flip_grid_blocks(ctx->n_tiles + 1), FLIP_BLOCK, 0, st>>>(g, tx, ty, ctx->n_tiles, ctx->band, ctx->tile_scan);
+        FLIP_LAUNCH_CHECK();
+        if (int rc = flip_exclusive_scan(ctx, ctx->tile_scan, ctx->n_tiles + 1)) return rc;
+        k_gather_tile_list<<<flip_grid_blocks(ctx->n_tiles), FLIP_BLOCK, 0, st>>>(ctx->n_tiles, ctx->tile_scan, ctx->tile_list);
+        FLIP_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
@@ -355,14 +401,7 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
     FLIP_LAUNCH_CHECK();
     k_band_axis<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, 2, ctx->tmp_u8, ctx->band);
     FLIP_LAUNCH_CHECK();
-    {   // the tiles of the LDS-staged gather that hold a cell of the band
-        const int tx = (ctx->g.nx + GT_T - 1) / GT_T, ty = (ctx->g.ny + GT_T - 1) / GT_T;
-        k_gather_tile_flags<<<flip_grid_blocks(ctx->n_tiles + 1), FLIP_BLOCK, 0, st>>>(g, tx, ty, ctx->n_tiles, ctx->band, ctx->tile_scan);
-        FLIP_LAUNCH_CHECK();
-        if (int rc = flip_exclusive_scan(ctx, ctx->tile_scan, ctx->n_tiles + 1)) return rc;
-        k_gather_tile_list<<<flip_grid_blocks(ctx->n_tiles), FLIP_BLOCK, 0, st>>>(ctx->n_tiles, ctx->tile_scan, ctx->tile_list);
-        FLIP_LAUNCH_CHECK();
-    }
+    if (int rc = build_gather_lists(ctx)) return rc;
     ctx->binned = true;
     ctx->slots_valid = true;
     if (n_outside) {
@@ -413,11 +452,12 @@ extern "C" int flip_binning_download(flip_ctx *ctx, int32_t *cell_id, int32_t *c
 // calls, so one walk over the particles serves both; flip_density() launches the density-only form when the fused
 // result is stale).
 //
-// One thread per cell of the band.  Its particles are the 16 runs of the half-cell order described above.  The runs
-// of a lane are 0 to ~10 records long and differ from lane to lane, so a loop per run would idle most of the wave most
-// of the time; instead every lane walks ONE flat sequence -- its non-empty runs back to back, their (first, end) pairs
-// parked in LDS because the run number is a per-lane variable -- and the wave iterates max-over-lanes of the total,
-// which at 8 particles per cell is 64 +- 8.  The next record is requested before the current one is consumed.
+// One thread per slot of the work list: a column of RY cells in each of RZ planes (2 x 2 by default), all of which lie
+// in the band or the thread skips them.  The particles of a cell are the 16 runs of the half-cell order described above.
+// The runs of a lane are 0 to ~10 records long and differ from lane to lane, so a loop per run would idle most of the
+// wave most of the time; instead every lane walks ONE flat sequence -- its non-empty runs back to back, their
+// (first, end) pairs parked in LDS because the run number is a per-lane variable -- and the wave iterates
+// max-over-lanes of the total.  Records are requested two steps before they are consumed.
 // Accumulation order = run order = the order stated at d_upper_half.
 struct DensityArgs {
     const float *phi;
@@ -427,43 +467,39 @@ struct DensityArgs {
     double vs3;
 };
 
-// RY cells of a y-column per thread (1 or 2): the runs around them are walked once for all of them ((2 RY + 2) x 4 runs
-// instead of 16 RY), which removes loads and loop overhead, not arithmetic; every cell still meets its particles in its
-// own order.  Which cells a run feeds travels in the spare top bits of its (first, end) pair.
+// RY x RZ cells per thread (a y-column of RY cells in each of RZ planes): the runs around them are walked once for all of
+// them ((2 RY + 2) x (2 RZ + 2) runs instead of 16 RY RZ), which removes loads and loop overhead, not arithmetic; every
+// cell still meets its particles in its own order (the run order restricted to the runs of one cell's support is that
+// cell's (dk, dj, hz, hy) order, because the cell offsets only shift dk and dj).  Which cells a run feeds travels in the
+// spare top two bits of each half of its (first, end) pair, which is why a context holds fewer than 2^30 particles.
 // The density term divides by a per-cell constant: a / b is evaluated as q0 = a * y, q = fma(fma(-q0, b, a), y, q0) with
 // y = 1 / b rounded once per cell, which yields the correctly rounded quotient (the residual a - q0 b is exact in the
 // fused operation, and one correction of a product that is already within an ulp lands on the nearest double) at three
 // instructions instead of the fifteen of a division.
-template <bool P2G, int RY>
-__global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, int nyb, const int32_t *__restrict__ sub_start, const uint8_t *__restrict__ band,
-                                                      const flip_ppos *__restrict__ pm, const flip_pvel *__restrict__ pv,
-                                                      double *__restrict__ u, double *__restrict__ v, double *__restrict__ w,
-                                                      uint8_t *__restrict__ active, DensityArgs da) {
-    constexpr int NRUN = (2 * RY + 2) * 4;
-    __shared__ int2 runs[NRUN][FLIP_BLOCK];
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)g.nx * nyb * g.nz) return;
+template <bool P2G, int RY, int RZ, int DEPTH>
+__device__ __forceinline__ void d_gather_slot(const GridDims &g, int nyb, long long t, int2 (*runs)[FLIP_BLOCK], const int32_t *__restrict__ sub_start,
+                                              const uint8_t *__restrict__ band, const flip_ppos *__restrict__ pm, const flip_pvel *__restrict__ pv,
+                                              double *__restrict__ u, double *__restrict__ v, double *__restrict__ w,
+                                              uint8_t *__restrict__ active, const DensityArgs &da) {
+    constexpr int NC = RY * RZ;
+    static_assert(NC <= 4, "the feed mask has four bits");
     const int tid = threadIdx.x;
     const int i = (int)(t % g.nx);
     const long long tq = t / g.nx;
-    const int j0 = (int)(tq % nyb) * RY, k = (int)(tq / nyb);
+    const int j0 = (int)(tq % nyb) * RY, k0 = (int)(tq / nyb) * RZ;
     const float *__restrict__ phi = da.phi;
-    bool live[RY], with_density[RY];
-    float fw[RY], dens[RY];
-    double denom[RY], rden[RY];
+    bool live[NC], with_density[NC];
+    float fw[NC], dens[NC];
+    double denom[NC], rden[NC];
     bool any_live = false, any_walk = false;
 #pragma unroll
-    for (int r = 0; r < RY; ++r) {
-        const int j = j0 + r;
+    for (int r = 0; r < NC; ++r) {
+        const int j = j0 + r % RY, k = k0 + r / RY;
         live[r] = false; with_density[r] = false;
         fw[r] = 0.f; dens[r] = 0.f; denom[r] = 1.0; rden[r] = 1.0;
-        if (j >= g.ny) continue;
+        if (j >= g.ny || k >= g.nz) continue;
         const long long c = d_lid(g, i, j, k);
-        if (!(band[c] & 2)) {
-            if (P2G) { u[c] = 0.0; v[c] = 0.0; w[c] = 0.0; active[c] = 0; }
-            da.density[c] = 0.f;
-            continue;
-        }
+        if (!(band[c] & 2)) continue;   // its zeros are k_gather_clear's
         live[r] = true;
         any_live = true;
         const float pc = phi[c];
@@ -481,8 +517,8 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, int nyb, cons
         const int sxa = i > 0 ? 2 * i - 1 : 0, sxb = i < g.nx - 1 ? 2 * i + 2 : 2 * g.nx - 1;
         const int nx2 = 2 * g.nx;
 #pragma unroll
-        for (int dk = -1; dk <= 1; ++dk) {
-            const int kk = k + dk;
+        for (int dk = -1; dk <= RZ; ++dk) {
+            const int kk = k0 + dk;
             if (kk < 0 || kk >= g.nz) continue;
 #pragma unroll
             for (int dj = -1; dj <= RY; ++dj) {
@@ -490,21 +526,23 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, int nyb, cons
                 if (jj < 0 || jj >= g.ny) continue;
                 const long long rowbase = ((long long)kk * g.ny + jj) * (4LL * nx2);
 #pragma unroll
-                for (int hz = (dk < 0 ? 1 : 0); hz <= (dk > 0 ? 0 : 1); ++hz) {
+                for (int hz = (dk < 0 ? 1 : 0); hz <= (dk >= RZ ? 0 : 1); ++hz) {
 #pragma unroll
                     for (int hy = (dj < 0 ? 1 : 0); hy <= (dj >= RY ? 0 : 1); ++hy) {
-                        // half-cell row 2 dj + hy (relative to the column's first cell) lies in the support of cell r iff
-                        // 2 r - 1 <= 2 dj + hy <= 2 r + 2
-                        const int rel = 2 * dj + hy;
+                        // half-cell row 2 dj + hy (relative to the thread's first cell) lies in the support of a cell at
+                        // offset ry iff 2 ry - 1 <= 2 dj + hy <= 2 ry + 2; the same along z
+                        const int rely = 2 * dj + hy, relz = 2 * dk + hz;
                         unsigned feeds = 0;
 #pragma unroll
-                        for (int r = 0; r < RY; ++r)
-                            if (live[r] && rel >= 2 * r - 1 && rel <= 2 * r + 2) feeds |= 1u << r;
+                        for (int r = 0; r < NC; ++r) {
+                            const int ry = r % RY, rz = r / RY;
+                            if (live[r] && rely >= 2 * ry - 1 && rely <= 2 * ry + 2 && relz >= 2 * rz - 1 && relz <= 2 * rz + 2) feeds |= 1u << r;
+                        }
                         if (!feeds) continue;
                         const int32_t *row = sub_start + rowbase + (long long)(hz * 2 + hy) * nx2;
                         const int32_t s0 = row[sxa], s1 = row[sxb + 1];
                         if (s0 < s1) {
-                            runs[nr][tid] = make_int2((int)((unsigned)s0 | ((feeds & 1u) << 31)), (int)((unsigned)s1 | ((feeds >> 1) << 31)));
+                            runs[nr][tid] = make_int2((int)((unsigned)s0 | ((feeds & 3u) << 30)), (int)((unsigned)s1 | ((feeds >> 2) << 30)));
                             ++nr;
                         }
                     }
@@ -513,85 +551,117 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, int nyb, cons
         }
     }
     const double eps = (double)10e-37f; // background of the weight grid (src/FluidSimulator.cpp:32,77)
-    double ws0[RY], ws1[RY], ws2[RY], a0[RY], a1[RY], a2[RY], cy[RY];
+    double ws0[NC], ws1[NC], ws2[NC], a0[NC], a1[NC], a2[NC];
 #pragma unroll
-    for (int r = 0; r < RY; ++r) {
+    for (int r = 0; r < NC; ++r) {
         ws0[r] = ws1[r] = ws2[r] = eps;
         a0[r] = a1[r] = a2[r] = 0.0;
-        cy[r] = (double)(g.oy + j0 + r);
     }
-    const double cx = (double)(g.ox + i), cz = (double)(g.oz + k);
+    double cy[RY], cz[RZ];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) cy[r] = (double)(g.oy + j0 + r);
+#pragma unroll
+    for (int r = 0; r < RZ; ++r) cz[r] = (double)(g.oz + k0 + r);
+    const double cx = (double)(g.ox + i);
     if (nr > 0) {
+        // cursor of the flat sequence: the record about to be requested
         int r_idx = 0;
         int2 cur = runs[0][tid];
-        unsigned feeds = ((unsigned)cur.x >> 31) | (((unsigned)cur.y >> 31) << 1);
-        int32_t s = cur.x & 0x7fffffff, e = cur.y & 0x7fffffff;
-        const double2 *rec = reinterpret_cast<const double2 *>(pm + 2 * (long long)s);
-        double2 p0 = rec[0], p1 = rec[1]; // (x, y) (z, mass)
-        double2 q0 = make_double2(0.0, 0.0), q1 = q0;
-        if (P2G) {
-            const double2 *vel = reinterpret_cast<const double2 *>(pv + 2 * (long long)s);
-            q0 = vel[0]; q1 = vel[1]; // (vx, vy) (vz, -)
-        }
+        unsigned feeds = ((unsigned)cur.x >> 30) | (((unsigned)cur.y >> 30) << 2);
+        int32_t s = cur.x & 0x3fffffff, e = cur.y & 0x3fffffff;
         bool more = true;
-        while (more) {
-            const double2 r0 = p0, r1 = p1, r2 = q0, r3 = q1;
-            const unsigned fd = feeds;
-            // step to the next record of the flat sequence and request it
-            ++s;
-            if (s == e) {
-                ++r_idx;
-                more = r_idx < nr;
-                if (more) {
-                    cur = runs[r_idx][tid];
-                    feeds = ((unsigned)cur.x >> 31) | (((unsigned)cur.y >> 31) << 1);
-                    s = cur.x & 0x7fffffff; e = cur.y & 0x7fffffff;
-                }
-            }
+        // DEPTH records are in flight per lane: slot d is requested DEPTH steps before it is consumed, so the latency of a
+        // record overlaps the arithmetic of the DEPTH - 1 before it (one record in flight leaves the lane idle for most
+        // of a round trip; the kernel is bound by that latency, not by the number of requests)
+        double2 b0[DEPTH], b1[DEPTH], b2[DEPTH], b3[DEPTH];
+        unsigned bf[DEPTH];
+        bool have[DEPTH];
+        auto request = [&](int d) {
+            have[d] = more;
             if (more) {
-                rec = reinterpret_cast<const double2 *>(pm + 2 * (long long)s);
-                p0 = rec[0]; p1 = rec[1];
+                const double2 *rec = reinterpret_cast<const double2 *>(pm + 2 * (long long)s);
+                b0[d] = rec[0]; b1[d] = rec[1]; // (x, y) (z, mass)
                 if (P2G) {
                     const double2 *vel = reinterpret_cast<const double2 *>(pv + 2 * (long long)s);
-                    q0 = vel[0]; q1 = vel[1];
+                    b2[d] = vel[0]; b3[d] = vel[1]; // (vx, vy) (vz, -)
+                }
+                bf[d] = feeds;
+                ++s;
+                if (s == e) {
+                    ++r_idx;
+                    more = r_idx < nr;
+                    if (more) {
+                        cur = runs[r_idx][tid];
+                        feeds = ((unsigned)cur.x >> 30) | (((unsigned)cur.y >> 30) << 2);
+                        s = cur.x & 0x3fffffff; e = cur.y & 0x3fffffff;
+                    }
                 }
             }
-            const double d0 = r0.x - cx, d2 = r1.x - cz;
-            // inside the support the hat function is 1 - |x| (1 + x for a negative x is the same IEEE operation), and the
-            // shifted argument x + 1/2 lies in [-1/2, 3/2], so only its upper cut-off needs a test
-            const double hx = d_hat_in(d0), hz = d_hat_in(d2);
-            const float mass = __int_as_float((int)(__double_as_longlong(r1.y) & 0xffffffffLL));
-            const float x0 = (float)hx, z0 = (float)hz;
-            const float x1 = (float)d_hat_up(d0 + 0.5), z1 = (float)d_hat_up(d2 + 0.5);
+        };
 #pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                if (RY > 1 && !((fd >> r) & 1u)) continue;
-                const double d1 = r0.y - cy[r];
-                const double hy = d_hat_in(d1);
-                const double wgt = hx * hy * hz;
-                if (with_density[r] && wgt > 0) {
-                    const double a = wgt * (double)mass;
-                    const double qa = a * rden[r];
-                    const double quot = fma(fma(-qa, denom[r], a), rden[r], qa); // = a / denom[r], correctly rounded
-                    const double add = (double)0.f + quot;
-                    dens[r] = (float)((double)dens[r] + add);
+        for (int d = 0; d < DEPTH; ++d) {
+            b0[d] = b1[d] = b2[d] = b3[d] = make_double2(0.0, 0.0);
+            bf[d] = 0;
+            request(d);
+        }
+        while (have[0]) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (!have[d]) break;
+                const double2 r0 = b0[d], r1 = b1[d], r2 = b2[d], r3 = b3[d];
+                const unsigned fd = bf[d];
+                request(d);
+                const double d0 = r0.x - cx;
+                // inside the support the hat function is 1 - |x| (1 + x for a negative x is the same IEEE operation), and the
+                // shifted argument x + 1/2 lies in [-1/2, 3/2], so only its upper cut-off needs a test
+                const double hx = d_hat_in(d0);
+                const float mass = __int_as_float((int)(__double_as_longlong(r1.y) & 0xffffffffLL));
+                const float x0 = (float)hx;
+                const float x1 = (float)d_hat_up(d0 + 0.5);
+                double hyv[RY], hzv[RZ];
+                float y0v[RY], y1v[RY], z0v[RZ], z1v[RZ];
+#pragma unroll
+                for (int q = 0; q < RY; ++q) {
+                    const double d1 = r0.y - cy[q];
+                    hyv[q] = d_hat_in(d1);
+                    y0v[q] = (float)hyv[q];
+                    y1v[q] = (float)d_hat_up(d1 + 0.5);
                 }
-                if (P2G) {
-                    const float y0 = (float)hy;
-                    const float y1 = (float)d_hat_up(d1 + 0.5);
-                    const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
-                    if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
-                        ws0[r] = ws0[r] + w0; ws1[r] = ws1[r] + w1; ws2[r] = ws2[r] + w2;
-                        a0[r] = a0[r] + w0 * r2.x; a1[r] = a1[r] + w1 * r2.y; a2[r] = a2[r] + w2 * r3.x;
+#pragma unroll
+                for (int q = 0; q < RZ; ++q) {
+                    const double d2 = r1.x - cz[q];
+                    hzv[q] = d_hat_in(d2);
+                    z0v[q] = (float)hzv[q];
+                    z1v[q] = (float)d_hat_up(d2 + 0.5);
+                }
+#pragma unroll
+                for (int r = 0; r < NC; ++r) {
+                    if (NC > 1 && !((fd >> r) & 1u)) continue;
+                    const int ry = r % RY, rz = r / RY;
+                    const double wgt = hx * hyv[ry] * hzv[rz];
+                    if (with_density[r] && wgt > 0) {
+                        const double a = wgt * (double)mass;
+                        const double qa = a * rden[r];
+                        const double quot = fma(fma(-qa, denom[r], a), rden[r], qa); // = a / denom[r], correctly rounded
+                        const double add = (double)0.f + quot;
+                        dens[r] = (float)((double)dens[r] + add);
+                    }
+                    if (P2G) {
+                        const float y0 = y0v[ry], y1 = y1v[ry], z0 = z0v[rz], z1 = z1v[rz];
+                        const double w0 = (double)(x1 * y0 * z0), w1 = (double)(x0 * y1 * z0), w2 = (double)(x0 * y0 * z1);
+                        if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
+                            ws0[r] = ws0[r] + w0; ws1[r] = ws1[r] + w1; ws2[r] = ws2[r] + w2;
+                            a0[r] = a0[r] + w0 * r2.x; a1[r] = a1[r] + w1 * r2.y; a2[r] = a2[r] + w2 * r3.x;
+                        }
                     }
                 }
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < RY; ++r) {
+    for (int r = 0; r < NC; ++r) {
         if (!live[r]) continue;
-        const long long c = d_lid(g, i, j0 + r, k);
+        const long long c = d_lid(g, i, j0 + r % RY, k0 + r / RY);
         if (P2G) {
             u[c] = a0[r] / ws0[r];
             v[c] = a1[r] / ws1[r];
@@ -602,6 +672,49 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, int nyb, cons
         if (0 < fw[r] && fw[r] < 6) dn = dn > da.rest ? dn : da.rest;
         da.density[c] = dn;
         if ((double)dn > 1.5 * (double)da.rest) atomicAdd(da.n_over, 1);
+    }
+}
+
+// The cells outside the band: zero velocity, inactive, zero density (the reference's grids have no voxel there).
+template <bool P2G>
+__global__ void k_gather_clear(long long B, const uint8_t *__restrict__ band, double *__restrict__ u, double *__restrict__ v,
+                               double *__restrict__ w, uint8_t *__restrict__ active, float *__restrict__ density) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B || (band[c] & 2)) return;
+    if (P2G) { u[c] = 0.0; v[c] = 0.0; w[c] = 0.0; active[c] = 0; }
+    density[c] = 0.f;
+}
+// Persistent workgroups over the work list (k_gather_slot_flags): a workgroup claims 256 consecutive entries at a time,
+// a few neighbouring rows of slots, whose waves read many of the same records while they are in the CU's L1 (waves that
+// claim on their own end up on different CUs: 857 against 786 us at 256^3).  The kernel is bound by the L1 misses a CU
+// can have in flight, not by its request or arithmetic rate, which is also why more than two or three workgroups per CU
+// make it slower.  The list is cut into eight contiguous parts, one per XCD (workgroups with the same blockIdx % 8 share an
+// XCD and its L2 under round-robin dispatch), each with a claim counter of its own.  A workgroup whose part is used up
+// goes on to the following parts, at most once round, and leaves: no workgroup waits for another.
+template <bool P2G, int RY, int RZ, int DEPTH>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, int nyb, const int32_t *__restrict__ list, const int32_t *__restrict__ n_list,
+                                                      int32_t *__restrict__ claim, const int32_t *__restrict__ sub_start,
+                                                      const uint8_t *__restrict__ band, const flip_ppos *__restrict__ pm,
+                                                      const flip_pvel *__restrict__ pv, double *__restrict__ u, double *__restrict__ v,
+                                                      double *__restrict__ w, uint8_t *__restrict__ active, DensityArgs da) {
+    constexpr int NRUN = (2 * RY + 2) * (2 * RZ + 2);
+    __shared__ int2 runs[NRUN][FLIP_BLOCK];
+    __shared__ int block_claim;
+    const int n = *n_list;
+    const int home = blockIdx.x & 7;
+    const int chunks = (n + FLIP_BLOCK - 1) / FLIP_BLOCK;
+    for (int hop = 0; hop < 8; ++hop) {
+        const int part = (home + hop) & 7;
+        const int lo = (int)(((long long)chunks * part) >> 3), hi = (int)(((long long)chunks * (part + 1)) >> 3);
+        for (;;) {
+            __syncthreads();   // every thread has read the previous claim
+            if (threadIdx.x == 0) block_claim = lo + atomicAdd(claim + part, 1);
+            __syncthreads();
+            const int c = block_claim;
+            if (c >= hi) break;
+            const int q = c * FLIP_BLOCK + threadIdx.x;
+            if (q < n) d_gather_slot<P2G, RY, RZ, DEPTH>(g, nyb, list[q], runs, sub_start, band, pm, pv, u, v, w, active, da);
+        }
     }
 }
 
@@ -1043,6 +1156,16 @@ static int gather_column() {
     static const int v = [] { const char *e = getenv("FLIP_GATHER_COLUMN"); const int q = e ? atoi(e) : 2; return q == 1 ? 1 : 2; }();
     return v;
 }
+// planes per thread in the gathers: FLIP_GATHER_PLANES=1|2 (tuning aid)
+static int gather_planes() {
+    static const int v = [] { const char *e = getenv("FLIP_GATHER_PLANES"); const int q = e ? atoi(e) : 2; return q == 1 ? 1 : 2; }();
+    return v;
+}
+// records in flight per lane in the gathers: FLIP_GATHER_DEPTH=1|2|3 (tuning aid)
+static int gather_depth() {
+    static const int v = [] { const char *e = getenv("FLIP_GATHER_DEPTH"); const int q = e ? atoi(e) : 2; return q < 1 ? 1 : (q > 3 ? 3 : q); }();
+    return v;
+}
 // Which form of the gather a context uses: flip_set_gather_mode; FLIP_GATHER_TILE=1 makes the LDS-staged form the default
 // of new contexts (tuning aid).
 int flip_default_gather_mode() {
@@ -1078,17 +1201,29 @@ static void launch_gather(flip_ctx *ctx, const DensityArgs &da) {
     double *u = P2G ? ctx->vel[1][0] : nullptr, *v = P2G ? ctx->vel[1][1] : nullptr, *w = P2G ? ctx->vel[1][2] : nullptr;
     uint8_t *act = P2G ? ctx->active : nullptr;
     if (ctx->gather_mode == 1) {
+        if (ctx->slot_list_shape != -1 && build_gather_lists(ctx) != 0) return;   // the form was switched since the binning
         if (launch_gather_tile<P2G>(ctx, da, u, v, w, act) == hipSuccess) return;
         // fall through to the other form; the caller's launch check reports a failure of that one
     }
-    if (gather_column() == 2) {
-        const int nyb = (ctx->g.ny + 1) / 2;
-        k_gather<P2G, 2><<<flip_grid_blocks((long long)ctx->g.nx * nyb * ctx->g.nz), FLIP_BLOCK, 0, ctx->stream>>>(
-            flip_dims(ctx), nyb, ctx->sub_start, ctx->band, packed_pos(ctx), packed_vel(ctx), u, v, w, act, da);
-    } else {
-        k_gather<P2G, 1><<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), ctx->g.ny, ctx->sub_start, ctx->band,
-                                                                                  packed_pos(ctx), packed_vel(ctx), u, v, w, act, da);
-    }
+    const int ry = gather_column(), rz = gather_planes();
+    if (ctx->slot_list_shape != ry * 16 + rz && build_gather_lists(ctx) != 0) return;   // the form was switched since the binning
+    const int nyb = (ctx->g.ny + ry - 1) / ry, nzb = (ctx->g.nz + rz - 1) / rz;
+    const long long nslots = (long long)ctx->g.nx * nyb * nzb;
+    k_gather_clear<P2G><<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(ctx->B, ctx->band, u, v, w, act, da.density);
+    if (hipMemsetAsync(ctx->gather_claim, 0, 8 * sizeof(int32_t), ctx->stream) != hipSuccess) return;
+    // as many workgroups as stay resident at once (the run table in LDS allows three per CU, two with four cells per thread)
+    static const int per_cu_env = [] { const char *e = getenv("FLIP_GATHER_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (ry * rz > 2 ? 2 : 3);
+    const unsigned blocks = (unsigned)(((ctx->n_cu * per_cu + 7) / 8) * 8);
+#define FLIP_GATHER_LAUNCH(RY, RZ, D)                                                                                          \
+    k_gather<P2G, RY, RZ, D><<<blocks, FLIP_BLOCK, 0, ctx->stream>>>(flip_dims(ctx), nyb, ctx->slot_list, ctx->slot_scan + nslots, ctx->gather_claim, \
+                                                                    ctx->sub_start, ctx->band, packed_pos(ctx), packed_vel(ctx), u, v, w, act, da)
+    const int depth = gather_depth();
+    if (ry == 2 && rz == 2) { if (depth == 1) FLIP_GATHER_LAUNCH(2, 2, 1); else if (depth == 2) FLIP_GATHER_LAUNCH(2, 2, 2); else FLIP_GATHER_LAUNCH(2, 2, 3); }
+    else if (ry == 2) { if (depth == 1) FLIP_GATHER_LAUNCH(2, 1, 1); else if (depth == 2) FLIP_GATHER_LAUNCH(2, 1, 2); else FLIP_GATHER_LAUNCH(2, 1, 3); }
+    else if (rz == 2) { if (depth == 1) FLIP_GATHER_LAUNCH(1, 2, 1); else if (depth == 2) FLIP_GATHER_LAUNCH(1, 2, 2); else FLIP_GATHER_LAUNCH(1, 2, 3); }
+    else { if (depth == 1) FLIP_GATHER_LAUNCH(1, 1, 1); else if (depth == 2) FLIP_GATHER_LAUNCH(1, 1, 2); else FLIP_GATHER_LAUNCH(1, 1, 3); }
+#undef FLIP_GATHER_LAUNCH
 }
 
 static int ensure_records(flip_ctx *ctx) {
@@ -1639,8 +1774,11 @@ extern "C" int flip_density(flip_ctx *ctx, int64_t *n_overdense) {
 
 // ---------------------------------------------------------------------------------------------
 // Redistribution of the particles of over-dense cells (src/Functors.cpp:268-322): a cell whose density exceeds 1.5 rest
-// density has its n particles spread over the f^3 sub-cells of a lattice, f = the largest integer with f^3 <= n, in a
-// shuffled order, each at a uniform random offset inside its sub-cell.  The reference draws from a random_device-seeded
+// density has its n particles spread over the f^3 sub-cells of a lattice, f = floor(pow(n, 1./3.)) (:288), in a
+// shuffled order, each at a uniform random offset inside its sub-cell.  That expression is the largest integer with
+// f^3 <= n except at the perfect cubes n = k^3 with k >= 4, where the correctly rounded power with the exponent 1./3.
+// (below a third) falls just short of k and the floor gives k - 1; it is restated in integers here (checked against the
+// C library's pow for every n below 2^31 that is a cube, and for all n up to 2 * 10^5).  The reference draws from a random_device-seeded
 // global generator inside a TBB loop, so it does not reproduce itself; here every draw is the stateless hash of
 // headers/util.h:259-266 (randhash) keyed on (seed, cell, draw number), and every density is the value computed before
 // any particle moved.  One thread per cell; the shuffled list lives in the cell's own slots of a scratch array.
@@ -1666,6 +1804,7 @@ __global__ void k_redistribute(GridDims g, float rest, uint32_t seed, const floa
     if (m == 0) return;
     int f = 1;
     while ((long long)(f + 1) * (f + 1) * (f + 1) <= m) ++f;
+    if (f >= 4 && f * f * f == m) --f;
     const int32_t sub = f * f * f;
     int32_t *list = list_scratch + s0; // sub <= m entries
     for (int32_t a = 0; a < sub; ++a) list[a] = a;

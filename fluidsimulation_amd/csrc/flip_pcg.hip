@@ -1151,6 +1151,11 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
         int rc = flip_alloc_system(ctx);
         if (!rc && hipMalloc((void **)&ctx->cg_scan, (size_t)(ctx->B + 1) * 4) != hipSuccess)
             rc = flip_fail(ctx, "hipMalloc of the second system's scan scratch", __FILE__, __LINE__);
+        if (rc) {
+            // nothing of a half-allocated set may survive: the next call would allocate over its pointers
+            flip_free_system(ctx);
+            if (ctx->cg_scan) { (void)hipFree(ctx->cg_scan); ctx->cg_scan = nullptr; }
+        }
         flip_swap_systems(ctx);
         if (rc) return rc;
         ctx->other.allocated = true;
@@ -1174,18 +1179,26 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
         if (q == 1) flip_swap_systems(ctx);
         return r;
     };
+    // An error return must not leave work queued on the pair streams unordered against the context's stream: later calls
+    // on it touch the same arrays (density, labels, the system sets).  The error text of the failing call is kept.
+    auto bail = [&](int code) -> int {
+        const std::string text = ctx->err;
+        for (int q = 0; q < 2; ++q) (void)hipStreamSynchronize(ctx->pair_stream[q]);
+        ctx->err = text;
+        return code;
+    };
     rc = with_system(1, [&]() -> int {
         // the row count of index_cells sits with the system that was active then
         if (int r = flip_copy_i32(ctx, ctx->d_counts, ctx->other.d_counts, ctx->stream)) return r;
         if (int r = flip_build_system(ctx, FLIP_SOLVE_DENSITY, dt)) return r;
         return pcg_prepare(ctx, tol, max_iter, precond, run[1], "flip_solve_pair");
     });
-    if (rc) return rc;
+    if (rc) return bail(rc);
     rc = with_system(0, [&]() -> int {
         if (int r = flip_build_system(ctx, FLIP_SOLVE_DIVERGENCE, dt)) return r;
         return pcg_prepare(ctx, tol, max_iter, precond, run[0], "flip_solve_pair");
     });
-    if (rc) return rc;
+    if (rc) return bail(rc);
     if (ctx->profiling) {
         // the direction kernels bracketed by events run with the device to themselves: two iterations of the divergence
         // solve before the density solve's stream is released
@@ -1193,8 +1206,8 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
         // the set-up of the density system on the other stream must have drained first
         FLIP_CHECK(hipEventRecord(ctx->pair_event[2], ctx->pair_stream[1]));
         FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[0], ctx->pair_event[2], 0));
-        if ((rc = with_system(0, [&] { return pcg_batch_direct(ctx, run[0], 1, false); }))) return rc;
-        if ((rc = with_system(0, [&] { return pcg_batch_direct(ctx, run[0], 1, true); }))) return rc;
+        if ((rc = with_system(0, [&] { return pcg_batch_direct(ctx, run[0], 1, false); }))) return bail(rc);
+        if ((rc = with_system(0, [&] { return pcg_batch_direct(ctx, run[0], 1, true); }))) return bail(rc);
         FLIP_CHECK(hipEventRecord(ctx->pair_event[2], ctx->pair_stream[0]));
         FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[1], ctx->pair_event[2], 0));
     }
@@ -1206,7 +1219,7 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
             for (int q = 0; q < 2; ++q)
                 if (active[q]) {
                     const int batch = run[q].use_mg ? mg_next_batch(run[q].launched, expected[q]) : 32;
-                    if ((rc = with_system(q, [&] { return pcg_batch(ctx, run[q], batch, true); }))) return rc;
+                    if ((rc = with_system(q, [&] { return pcg_batch(ctx, run[q], batch, true); }))) return bail(rc);
                     if (!run[q].use_mg || mg_check_after(run[q].launched, expected[q]) || run[q].launched > run[q].max_iter) more = false;
                 }
         }
@@ -1222,7 +1235,7 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
     }
     PcgTail tail[2];
     for (int q = 0; q < 2; ++q)
-        if ((rc = with_system(q, [&] { return pcg_enqueue_tail(ctx, tail[q]); }))) return rc;
+        if ((rc = with_system(q, [&] { return pcg_enqueue_tail(ctx, tail[q]); }))) return bail(rc);
     for (int q = 0; q < 2; ++q) {
         FLIP_CHECK(hipStreamSynchronize(ctx->pair_stream[q]));
         // later work on the context's own stream is ordered after both solves

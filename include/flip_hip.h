@@ -207,12 +207,13 @@ int flip_swap_valid_masks(flip_ctx *ctx);
 /* max over the box of each velocity component (Grid::evalMinMax in compute_cfl,
  * src/FluidSimulator.cpp:448-458). */
 int flip_velocity_max(flip_ctx *ctx, double out_max[3]);
-/* flip_velocity_max for callers that cannot allocate.  No counterpart in the reference; it exists for code under HIP
- * graph capture, tight serving loops and harnesses that forbid hipMalloc: this call performs no device or host
- * allocation of any kind.  Its per-workgroup partial maxima live in a static device array of 96 KB that every GPU the
- * library runs on holds until the process ends.  Same result as flip_velocity_max, bit for bit.  Limit: boxes of at
- * most 67 108 864 cells (4096 workgroups x 16384 cells); larger ones are refused with an error.  All calls on one GPU
- * share that GPU's array: calls that overlap in time on one GPU (different contexts or streams) race. */
+/* flip_velocity_max for callers that cannot allocate.  No counterpart in the reference; it exists for tight serving
+ * loops and harnesses that forbid hipMalloc: this call performs no device or host allocation of any kind.  It still
+ * ends with a device-to-host copy of the three doubles and a stream synchronise, so it cannot be recorded into a HIP
+ * graph.  Its per-workgroup partial maxima live in a static device array of 96 KB that every GPU the library runs on
+ * holds until the process ends.  Same result as flip_velocity_max, bit for bit.  Limit: boxes of at most 67 108 864
+ * cells (4096 workgroups x 16384 cells); larger ones are refused with an error.  All calls on one GPU share that GPU's
+ * array: calls that overlap in time on one GPU (different contexts or streams) race. */
 int flip_velocity_max_static(flip_ctx *ctx, double out_max[3]);
 
 /* ---- pressure-solve preparation (src/FluidSimulator.cpp:482-492) --------------------------- */

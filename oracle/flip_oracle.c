@@ -559,8 +559,9 @@ ORC_EXPORT int64_t orc_density(const orc_grid *g, int64_t n, const double *pos, 
 /* keyed on (seed, cell, draw number), so that the result depends on nothing but its inputs */
 /* (parity unpinned, necessarily).  Per cell whose density exceeds 1.5 rest density:        */
 /*   n particles of the cell (:269-272, :285; the atlas box [c-1/2, c+1/2] is restated as   */
-/*   "binned in cell c"), f = the largest integer with f^3 <= n (:288; floor(pow(n, 1/3.))  */
-/*   lands one lower at some perfect cubes depending on the C library), a shuffled list of  */
+/*   "binned in cell c"), f = floor(pow(n, 1./3.)) as written at :288 -- the largest integer */
+/*   with f^3 <= n, except that 1./3. is below a third, so a perfect cube n = k^3 with       */
+/*   k >= 4 gives k - 1 (64 particles: a 3^3 lattice) --, a shuffled list of                 */
 /*   the f^3 sub-cells (:292-296; std::shuffle restated as Fisher-Yates from the top), and  */
 /*   the m-th particle in slot order goes to sub-cell list[m % f^3] at a uniform random      */
 /*   offset: corner + (i,j,k)/f + U/f with linearTo3d's index order (:305-315).             */
@@ -589,8 +590,7 @@ ORC_EXPORT int64_t orc_redistribute(const orc_grid *g, int64_t n, double *pos, c
         if (!((double)density[c] > 1.5 * (double)rest_density)) continue;
         const int32_t s0 = cell_start[c], m = cell_start[c + 1] - s0;
         if (m == 0) continue;
-        int f = 1;
-        while ((int64_t)(f + 1) * (f + 1) * (f + 1) <= m) ++f;
+        const int f = (int)floor(pow((double)m, 1. / 3.));
         const int32_t sub = f * f * f;
         if (sub > cap) { cap = sub; list = (int32_t *)realloc(list, (size_t)cap * sizeof(int32_t)); }
         for (int32_t a = 0; a < sub; ++a) list[a] = a;

@@ -1,5 +1,6 @@
 # Collects the per-round evidence of the default bench command into gpurun_out/prof_<tag>/ (copy what is to be judged
 # into profiles/): the bench line, the rocprofv3 kernel statistics, and FETCH_SIZE / WRITE_SIZE in passes of their own.
+# Every pass runs the same command (same --steps / --warmup), so the counters see the scene state the line was timed on.
 # usage (on the GPU box, from the repository root): bash scripts/profile_round.sh TAG [bench args...]
 set -e
 tag=$1; shift
@@ -10,8 +11,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 python3 $root/bench.py "$@" > $out/line.json 2> $out/line.err
 tail -c 300 $out/line.json
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --no-cpu-baseline "$@" > $out/stats.log 2>&1
-timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > $out/pmc_fetch.log 2>&1
-timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > $out/pmc_write.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --no-cpu-baseline "$@" > $out/pmc_fetch.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py --no-cpu-baseline "$@" > $out/pmc_write.log 2>&1
 f=$(find $out/pmc_fetch -name "*counter_collection.csv" | head -1)
 w=$(find $out/pmc_write -name "*counter_collection.csv" | head -1)
 python3 $root/profiles/summarize_pmc.py $f FETCH_SIZE $out/pmc_fetch_size.csv

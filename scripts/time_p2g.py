@@ -15,7 +15,7 @@ with FlipContext(sc.desc()) as c:
         for _ in range(reps):
             e0.record(); fn(); e1.record(); e1.synchronize(); tot += e0.elapsed_time(e1)
         return tot / reps
-    print(f"column {os.environ.get('FLIP_GATHER_COLUMN', 'default')}: p2g {t(c.p2g) * 1e3:.0f} us", flush=True)
+    print(f"column {os.environ.get('FLIP_GATHER_COLUMN', 'default')} planes {os.environ.get('FLIP_GATHER_PLANES', 'default')}: p2g {t(c.p2g) * 1e3:.0f} us", flush=True)
     def dens():
         c.upload("phi_fluid", sc.phi_fluid); c.density(want_count=False)
     def up():

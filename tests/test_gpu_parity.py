@@ -716,6 +716,51 @@ def test_redistribution_of_overdense_cells_matches_the_oracle():
         assert not np.array_equal(pos2, pos) and np.array_equal(np.any(pos2 != sc.pos, axis=1), changed)
 
 
+def test_redistribution_lattice_at_perfect_cube_counts():
+    """src/Functors.cpp:288 sizes the lattice with floor(pow(n, 1./3.)), which gives 3 for 64 particles and 4 for 125 (the
+    exponent is below a third); the oracle evaluates that expression with the C library, the device restates it in
+    integers.  Cells with exactly 27, 64, 125 and 126 particles."""
+    sc = scenes.cube_drop(16, ppc=8, seed=5, exact_levelset=False)
+    o = Oracle(sc.desc())
+    cell_id, cell_start, _, _ = o.bin_particles(sc.pos)
+    counts = np.diff(cell_start[: sc.n_cells + 1])
+    filled = np.nonzero(counts == 8)[0]
+    rng = np.random.default_rng(8)
+    extra = []
+    targets = dict(zip(filled[[10, 80, 150, 220]], (27, 64, 125, 126)))
+    for c, total in targets.items():
+        k, j, i = np.unravel_index(c, (sc.dims[2], sc.dims[1], sc.dims[0]))
+        centre = np.array([sc.origin[0] + i, sc.origin[1] + j, sc.origin[2] + k], dtype=np.float64)
+        extra.append(centre + rng.uniform(-0.45, 0.45, (total - 8, 3)))
+    pos = np.concatenate([sc.pos] + extra)
+    vel = np.zeros_like(pos)
+    mass = np.full(pos.shape[0], sc.mass[0] * 4.0, dtype=np.float32)
+    cell_id, cell_start, perm, _ = o.bin_particles(pos)
+    counts = np.diff(cell_start[: sc.n_cells + 1])
+    assert all(counts[c] == t for c, t in targets.items())
+    band2 = o.particle_mask(cell_start, 2)
+    dens, _ = o.density(pos, mass, cell_start, perm, band2, sc.phi_fluid)
+    assert all(dens.ravel()[c] > 1.5 * sc.desc()["rest_density"] for c in targets)
+    want, cells, moved = o.redistribute(pos, cell_start, perm, dens, seed=77)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload("phi_solid", sc.phi_solid)
+        ctx.upload("phi_fluid", sc.phi_fluid)
+        ctx.upload_particles(pos, vel, mass)
+        ctx.bin_particles()
+        ctx.p2g()
+        assert (cells, moved) == ctx.redistribute_overdense(77)
+        got, _ = ctx.download_particles()
+    assert np.array_equal(got, want)
+    # the lattice the 64-particle cell received: 27 sub-cells of a third of a cell, not 64 of a quarter
+    c64 = [c for c, t in targets.items() if t == 64][0]
+    k, j, i = np.unravel_index(c64, (sc.dims[2], sc.dims[1], sc.dims[0]))
+    corner = np.array([sc.origin[0] + i, sc.origin[1] + j, sc.origin[2] + k]) - 0.5
+    inside = got[cell_id == c64]
+    assert len({tuple(v) for v in np.floor((inside - corner) * 3).astype(int)}) == 27
+    occupancy = np.unique(np.floor((inside - corner) * 3).astype(int), axis=0, return_counts=True)[1]
+    assert occupancy.min() >= 2 and occupancy.max() <= 3
+
+
 def test_particle_advection_matches_the_oracle_restatement():
     """flip_advect_particles against orc_advect_particles (RK3 + push-out, src/FluidDomain.cpp:63-75; OpenVDB's
     PointAdvect / cpt restated on both sides, parity unpinned) on a random velocity field, with the floating sphere as a

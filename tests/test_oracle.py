@@ -339,3 +339,18 @@ def test_redistribution_restatement_properties():
     same, cells0, moved0 = o.redistribute(sc.pos, cell_start, perm, d0, seed=7)
     if n0 == 0:
         assert cells0 == 0 and moved0 == 0 and np.array_equal(same, sc.pos)
+
+
+def test_lattice_factor_rule_of_the_redistribution():
+    """floor(pow(n, 1./3.)) of src/Functors.cpp:288 against its restatement in integers (the device kernel's form): the
+    integer cube root, one lower at the perfect cubes k^3 with k >= 4."""
+    import math
+
+    def rule(n):
+        f = 1
+        while (f + 1) ** 3 <= n:
+            f += 1
+        return f - 1 if f >= 4 and f ** 3 == n else f
+
+    for n in list(range(1, 20000)) + [k ** 3 + d for k in range(27, 1290, 7) for d in (-1, 0, 1)]:
+        assert math.floor(math.pow(n, 1. / 3.)) == rule(n), n
