@@ -383,8 +383,7 @@ extern "C" int flip_dist_substep(flip_dist *d, float dt, const flip_dist_step_op
         if (body) DIST_FLIP(flip_constrain_velocity(c, 1));   // :405-408
     }
     DIST_FLIP(flip_update_diff(c));                           // :416
-    DIST_FLIP(flip_g2p(c, o->flip_pic_ratio));                // :420
-    if (o->advect) DIST_FLIP(flip_advect_particles(c, dt));   // :426
-    if (o->density_projection) DIST_FLIP(flip_apply_displacements(c)); // :429
+    // :420 transfer_from_grid_to_particles, :426 advectParticles, :429 apply_particle_displacements: one pass, same bits
+    DIST_FLIP(flip_update_particles(c, o->flip_pic_ratio, dt, o->advect, o->density_projection));
     return flip_dist_exchange_particles(d, nullptr, nullptr);
 }

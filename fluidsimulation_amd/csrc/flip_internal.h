@@ -279,7 +279,8 @@ int flip_fail_hip(flip_ctx *ctx, hipError_t e, const char *what, const char *fil
 // Dynamic LDS of the per-row reordering kernel (k_reorder_pack): 8 nx half-cell counters + 4 wave totals, and the upload
 // index (32 bit) and half-cell number (16 bit) of up to FLIP_ROW_QCAP particles of the row.
 #define FLIP_ROW_QCAP 6144
-static inline size_t flip_subrow_lds_bytes(int nx) { return ((size_t)8 * nx + 4) * sizeof(int32_t) + FLIP_ROW_QCAP * (sizeof(int32_t) + sizeof(uint16_t)); }
+static inline size_t flip_subrow_lds_bytes_for(int nx, int qcap) { return ((size_t)8 * nx + 4) * sizeof(int32_t) + (size_t)qcap * (sizeof(int32_t) + sizeof(uint16_t)); }
+static inline size_t flip_subrow_lds_bytes(int nx) { return flip_subrow_lds_bytes_for(nx, FLIP_ROW_QCAP); }
 
 static inline int flip_grid_blocks(int64_t n) { return (int)((n + FLIP_BLOCK - 1) / FLIP_BLOCK); }
 

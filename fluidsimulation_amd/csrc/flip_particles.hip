@@ -115,9 +115,9 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_reorder_pack(GridDims g, const i
                                                             ParticlePtrs src, ParticlePtrs dst, int32_t *__restrict__ sub_start,
                                                             int32_t *__restrict__ sub_slot, int32_t *__restrict__ tmp_q,
                                                             flip_ppos *__restrict__ pcell, flip_ppos *__restrict__ pm,
-                                                            flip_pvel *__restrict__ pv) {
+                                                            flip_pvel *__restrict__ pv, int qcap) {
     extern __shared__ __align__(16) int32_t lds_words[];
-    int32_t *lds = lds_words; // [8 nx] counts, then exclusive offsets; [4] wave totals; [FLIP_ROW_QCAP] upload indices; [FLIP_ROW_QCAP / 2] half-cell numbers (16 bit)
+    int32_t *lds = lds_words; // [8 nx] counts, then exclusive offsets; [4] wave totals; [qcap] upload indices; [qcap / 2] half-cell numbers (16 bit)
     const int nsub = 8 * g.nx;
     const long long row = blockIdx.x;
     const long long c0 = row * g.nx;
@@ -132,8 +132,8 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_reorder_pack(GridDims g, const i
     }
     for (int q = tid; q < nsub; q += FLIP_BLOCK) lds[q] = 0;
     int32_t *kbuf = lds + nsub + 4;
-    uint16_t *qbuf = reinterpret_cast<uint16_t *>(kbuf + FLIP_ROW_QCAP);
-    const bool in_lds = r1 - r0 <= FLIP_ROW_QCAP; // uniform over the workgroup
+    uint16_t *qbuf = reinterpret_cast<uint16_t *>(kbuf + qcap);
+    const bool in_lds = r1 - r0 <= qcap; // uniform over the workgroup
     __syncthreads();
     const int j = (int)(row % g.ny), k = (int)(row / g.ny);
     for (int32_t s = r0 + tid; s < r1; s += FLIP_BLOCK) {
@@ -385,9 +385,15 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
     }
     // every grid row gathers its particles from the previous order and stores them in both orders (also with no particles:
     // the gathers read sub_start); the particles outside the box, behind the last row, keep the plain reorder
-    k_reorder_pack<<<(int)((long long)ctx->g.ny * ctx->g.nz), FLIP_BLOCK, subrow_lds_bytes(ctx), st>>>(
+    // LDS room for the upload indices and half-cell numbers of a row: four times the mean row, within [1024, FLIP_ROW_QCAP]
+    // (a row above it reads them from global memory instead); the smaller the table, the more rows a CU works on at once,
+    // and the kernel lives on the latency of its gathers
+    const long long rows = (long long)ctx->g.ny * ctx->g.nz;
+    long long qcap = ((4 * n / rows + 511) / 512) * 512;
+    qcap = qcap < 1024 ? 1024 : (qcap > FLIP_ROW_QCAP ? FLIP_ROW_QCAP : qcap);
+    k_reorder_pack<<<(int)rows, FLIP_BLOCK, flip_subrow_lds_bytes_for(ctx->g.nx, (int)qcap), st>>>(
         g, ctx->cell_start, ctx->slot_src, ctx->slot_key, particle_ptrs(ctx, src), particle_ptrs(ctx, dst), ctx->sub_start, ctx->sub_slot,
-        ctx->cell_id, ctx->pcell, packed_pos(ctx), packed_vel(ctx));
+        ctx->cell_id, ctx->pcell, packed_pos(ctx), packed_vel(ctx), (int)qcap);
     FLIP_LAUNCH_CHECK();
     if (n > 0) {
         k_reorder_outside<<<flip_grid_blocks(n), FLIP_BLOCK, 0, st>>>(n, ctx->cell_start + B, ctx->slot_src, ctx->slot_key, particle_ptrs(ctx, src),
@@ -1744,6 +1750,98 @@ extern "C" int flip_advect_particles(flip_ctx *ctx, float dt) {
     ctx->binned = false;
     ctx->density_valid = false;
     ctx->prec_valid = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The particle update of a substep in one pass: transfer_from_grid_to_particles, FluidDomain::advectParticles and
+// apply_particle_displacements (src/FluidSimulator.cpp:420, :426, :429) follow each other without anything in between
+// that touches the particles, every one of them is a loop over independent particles, and the three kernels above spend
+// their time reading and writing the same positions.  This kernel evaluates the same expressions in the same order on
+// every particle -- the values handed from one stage to the next stay in registers instead of going through memory, and
+// the first velocity sample of the integrator is the PIC sample of the transfer (same grid, same point) -- so the result
+// is the three calls' result bit for bit.
+template <bool ADVECT, bool DISPLACE>
+__global__ void __launch_bounds__(FLIP_BLOCK) k_update_particles(GridDims g, long long n, double *__restrict__ px, double *__restrict__ py, double *__restrict__ pz,
+                                   double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
+                                   const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
+                                   const double *__restrict__ du, const double *__restrict__ dv, const double *__restrict__ dw,
+                                   const double *__restrict__ ex, const double *__restrict__ ey, const double *__restrict__ ez,
+                                   float ratio, double dt_over_dx, double inv_dx, const float *__restrict__ phi_s, float bg_s,
+                                   const float *__restrict__ phi_o, float bg_o) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    double x = px[s], y = py[s], z = pz[s];
+    // k_g2p
+    const float one_minus = 1 - ratio;
+    const double pic0 = d_box_sample(g, u, x + 0.5, y, z);
+    const double pic1 = d_box_sample(g, v, x, y + 0.5, z);
+    const double pic2 = d_box_sample(g, w, x, y, z + 0.5);
+    const double dif0 = d_box_sample(g, du, x + 0.5, y, z);
+    const double dif1 = d_box_sample(g, dv, x, y + 0.5, z);
+    const double dif2 = d_box_sample(g, dw, x, y, z + 0.5);
+    const double f0 = vx[s] + dif0, f1 = vy[s] + dif1, f2 = vz[s] + dif2;
+    vx[s] = pic0 * (double)one_minus + f0 * (double)ratio;
+    vy[s] = pic1 * (double)one_minus + f1 * (double)ratio;
+    vz[s] = pic2 * (double)one_minus + f2 * (double)ratio;
+    if (ADVECT) { // k_advect
+        const double a0 = pic0, a1 = pic1, a2 = pic2;
+        const double h = 0.5 * dt_over_dx;
+        const double x1 = x + h * a0, y1 = y + h * a1, z1 = z + h * a2;
+        const double b0 = d_box_sample(g, u, x1 + 0.5, y1, z1), b1 = d_box_sample(g, v, x1, y1 + 0.5, z1), b2 = d_box_sample(g, w, x1, y1, z1 + 0.5);
+        const double x2 = x + dt_over_dx * (2.0 * b0 - a0), y2 = y + dt_over_dx * (2.0 * b1 - a1), z2 = z + dt_over_dx * (2.0 * b2 - a2);
+        const double c0 = d_box_sample(g, u, x2 + 0.5, y2, z2), c1 = d_box_sample(g, v, x2, y2 + 0.5, z2), c2 = d_box_sample(g, w, x2, y2, z2 + 0.5);
+        double nx_ = x + dt_over_dx * (a0 + 4.0 * b0 + c0) / 6.0;
+        double ny_ = y + dt_over_dx * (a1 + 4.0 * b1 + c1) / 6.0;
+        double nz_ = z + dt_over_dx * (a2 + 4.0 * b2 + c2) / 6.0;
+        const float phi = d_solid_sample(g, phi_s, bg_s, phi_o, bg_o, nx_, ny_, nz_);
+        if (phi <= 0.f) {
+            const double gx = (double)d_solid_sample(g, phi_s, bg_s, phi_o, bg_o, nx_ + 0.5, ny_, nz_)
+                              - (double)d_solid_sample(g, phi_s, bg_s, phi_o, bg_o, nx_ - 0.5, ny_, nz_);
+            const double gy = (double)d_solid_sample(g, phi_s, bg_s, phi_o, bg_o, nx_, ny_ + 0.5, nz_)
+                              - (double)d_solid_sample(g, phi_s, bg_s, phi_o, bg_o, nx_, ny_ - 0.5, nz_);
+            const double gz = (double)d_solid_sample(g, phi_s, bg_s, phi_o, bg_o, nx_, ny_, nz_ + 0.5)
+                              - (double)d_solid_sample(g, phi_s, bg_s, phi_o, bg_o, nx_, ny_, nz_ - 0.5);
+            const double len = sqrt(gx * gx + gy * gy + gz * gz);
+            if (len > 0.0) {
+                const double d = -(double)phi * inv_dx / len;
+                nx_ += d * gx; ny_ += d * gy; nz_ += d * gz;
+            }
+        }
+        x = nx_; y = ny_; z = nz_;
+    }
+    if (DISPLACE) { // k_apply_disp
+        const double e0 = d_box_sample(g, ex, x + 0.5, y, z);
+        const double e1 = d_box_sample(g, ey, x, y + 0.5, z);
+        const double e2 = d_box_sample(g, ez, x, y, z + 0.5);
+        x = x + e0; y = y + e1; z = z + e2;
+    }
+    if (ADVECT || DISPLACE) { px[s] = x; py[s] = y; pz[s] = z; }
+}
+
+extern "C" int flip_update_particles(flip_ctx *ctx, float flip_pic_ratio, float dt, int advect, int displace) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(!advect || dt > 0.f, "flip_update_particles: dt must be positive");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->n == 0) return 0;
+    double **q = ctx->p[ctx->cur];
+    const double inv_dx = 1.0 / (double)ctx->g.dx;
+#define FLIP_UPDATE_LAUNCH(A, D)                                                                                                      \
+    k_update_particles<A, D><<<flip_grid_blocks(ctx->n), FLIP_BLOCK, 0, ctx->stream>>>(                                               \
+        flip_dims(ctx), ctx->n, q[0], q[1], q[2], q[3], q[4], q[5], ctx->vel[0][0], ctx->vel[0][1], ctx->vel[0][2], ctx->vel[3][0],   \
+        ctx->vel[3][1], ctx->vel[3][2], ctx->disp[0], ctx->disp[1], ctx->disp[2], flip_pic_ratio, (double)dt * inv_dx, inv_dx,        \
+        ctx->phi_solid, ctx->g.phi_solid_bg, ctx->has_obj ? ctx->phi_obj : nullptr, ctx->phi_obj_bg)
+    if (advect && displace) FLIP_UPDATE_LAUNCH(true, true);
+    else if (advect) FLIP_UPDATE_LAUNCH(true, false);
+    else if (displace) FLIP_UPDATE_LAUNCH(false, true);
+    else FLIP_UPDATE_LAUNCH(false, false);
+#undef FLIP_UPDATE_LAUNCH
+    FLIP_LAUNCH_CHECK();
+    ctx->prec_valid = false; // velocities changed
+    if (advect || displace) {
+        ctx->binned = false; // positions moved: the sort is stale
+        ctx->density_valid = false;
+    }
     return 0;
 }
 

@@ -400,11 +400,7 @@ class DistributedSubstep:
             if self.rigid_body:
                 c.constrain_velocity(True)                          # :405-408
         c.update_diff()
-        c.g2p(self.ratio)
-        if self.advect:
-            c.advect_particles(dt)                                  # :426
-        if self.density_projection:
-            c.apply_displacements()
+        c.update_particles(self.ratio, dt, self.advect, self.density_projection)   # :420, :426, :429 in one pass
         if self.exchange is not None:
             out["exchange"] = self.exchange.run()
         return out

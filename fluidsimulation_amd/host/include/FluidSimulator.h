@@ -34,6 +34,8 @@ public:
     bool density_constraint = true;    // DENSITY_CONSTRAINT_PPE
     bool concurrent_solves = true;     // both systems assembled first and solved side by side (flip_solve_pair): the
                                        // density system does not depend on the divergence solve; same results
+    bool fused_particle_update = true; // the three particle updates that close a substep (src/FluidSimulator.cpp:420-429)
+                                       // as one device pass; false: the three calls of the reference's loop body
     bool advect = true;                // FluidDomain::advectParticles inside the substep
     bool constrain = true;             // the two constrain_velocity calls of the substep
     bool verbose = true;               // the reference prints per-substep timings

@@ -15,8 +15,10 @@ class FlipSubstep:
     def __init__(self, ctx: FlipContext, flip_pic_ratio: float = 0.95, tol: float = 1e-15, max_iter: int = 0,
                  precond: int = PRECOND_JACOBI, density_projection: bool = True, constrain: bool = False,
                  advect: bool = False, rigid_body: bool = False, levelset_radius: float | None = None,
-                 concurrent_solves: bool = False, redistribute_seed: int | None = None):
+                 concurrent_solves: bool = False, redistribute_seed: int | None = None, fused_particle_update: bool = True):
         self.ctx = ctx
+        # the three particle updates that close the substep as one kernel (same bits) or as the three calls
+        self.fused_particle_update = fused_particle_update
         # the density system does not depend on the divergence solve: both can be assembled first and solved side by side
         self.concurrent_solves = concurrent_solves and density_projection
         self.ratio = flip_pic_ratio      # main.cpp:167
@@ -73,10 +75,13 @@ class FlipSubstep:
         c.extrapolate(2)                          # :398
         self._constrain()
         c.update_diff()                           # :416
-        c.g2p(self.ratio)                         # :420
-        if self.advect:
-            c.advect_particles(dt)                # :426
-        if self.density_projection:
-            c.apply_displacements()               # :429
+        if self.fused_particle_update:
+            c.update_particles(self.ratio, dt, self.advect, self.density_projection)   # :420, :426, :429 in one pass
+        else:
+            c.g2p(self.ratio)                         # :420
+            if self.advect:
+                c.advect_particles(dt)                # :426
+            if self.density_projection:
+                c.apply_displacements()               # :429
         self.info = {"divergence": info_div, "density": info_den}
         return self.info

@@ -175,6 +175,12 @@ int flip_g2p(flip_ctx *ctx, float flip_pic_ratio);
 /* FluidSimulator::apply_particle_displacements (src/FluidSimulator.cpp:137-151). */
 int flip_apply_displacements(flip_ctx *ctx);
 
+/* The three particle updates that close a substep in one pass over the particles: flip_g2p(flip_pic_ratio), then, if
+ * advect != 0, flip_advect_particles(dt), then, if displace != 0, flip_apply_displacements -- the order of
+ * src/FluidSimulator.cpp:420, :426, :429.  Same result as the three calls, bit for bit; one read and one write of every
+ * position instead of three. */
+int flip_update_particles(flip_ctx *ctx, float flip_pic_ratio, float dt, int advect, int displace);
+
 /* FluidDomain::advectParticles (src/FluidDomain.cpp:63-75) with ParticleSet::advectAndEnsureOutsideObstacles
  * (src/ParticleSet.cpp:18-45): RK3 through velFront, then particles inside the container wall or the rigid
  * body are moved to its surface along the level-set gradient (the reference samples an OpenVDB closest-point

@@ -22,6 +22,7 @@ GROUPS = {
     "k_mg_smooth": ["void k_mg_smooth<float, true>"],
     "k_gather": ["void k_gather<true, 2, 2, 2>", "void k_gather_clear<true>"],
     "k_g2p": ["k_g2p"],
+    "k_update_particles": ["void k_update_particles<true, true>"],
     "k_fluid_levelset": ["k_near_x", "k_near_axis", "void k_fluid_levelset_near<3>", "k_fluid_levelset_list", "k_fluid_levelset_far"],
     "binning": ["k_cell_ids", "k_scatter_slots", "k_reorder_pack", "k_reorder_outside", "k_band_x", "k_band_axis"],
 }

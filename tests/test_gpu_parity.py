@@ -1202,3 +1202,29 @@ def test_the_pcgsolver_stopping_rule_is_reported(precond):
         assert true_ratio <= 1.5e-12 and abs(true_ratio - at["rel_residual_inf"]) <= 0.05 * at["rel_residual_inf"] + 1e-15, (true_ratio, at)
         before = ctx.pcg_solve(1e-15, k - 1, precond)
         assert before["iterations"] == k - 1 and before["iterations_inf"] == -1 and before["rel_residual_inf"] > 1e-12, before
+
+
+@pytest.mark.parametrize("advect,displace,body", [(True, True, False), (True, False, False), (False, True, False), (False, False, False),
+                                                   (True, True, True)])
+def test_the_one_pass_particle_update_is_the_three_calls(advect, displace, body):
+    """flip_update_particles = flip_g2p, flip_advect_particles, flip_apply_displacements (src/FluidSimulator.cpp:420, :426,
+    :429) in one kernel: positions and velocities after three substeps must equal those of the three calls bit for bit,
+    with every combination of the two optional stages and with the rigid body's push-out."""
+    from fluidsimulation_amd import FlipSubstep, PRECOND_MULTIGRID
+    sc = scenes.cube_drop(24, ppc=4, seed=9)
+    if body:
+        sc = scenes.add_sphere(sc, vel=(0.1, -0.3, 0.05, 0.4, -0.2, 0.3))
+    rng = np.random.default_rng(17)
+    sc.vel = rng.normal(0, 0.5, sc.pos.shape)
+    results = []
+    for fused in (False, True):
+        with FlipContext(sc.desc()) as ctx:
+            ctx.upload_scene(sc)
+            step = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, density_projection=displace, advect=advect, constrain=True, rigid_body=body,
+                               fused_particle_update=fused)
+            for _ in range(3):
+                step.step(0.004)
+            results.append(ctx.download_particles())
+    (pa, va), (pb, vb) = results
+    assert np.array_equal(pa, pb) and np.array_equal(va, vb)
+    assert np.abs(va - sc.vel).max() > 0 and (not (advect or displace) or np.abs(pa - sc.pos).max() > 0)
