@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--sequential-solves", action="store_true",
                     help="N = 1: divergence solve, projection, density solve one after the other (the reference's order) instead "
                          "of both solves side by side on two streams")
+    ap.add_argument("--python-driver", action="store_true",
+                    help="one GPU: the substep as a sequence of C-ABI calls from Python (fluidsimulation_amd.substep) instead of one "
+                         "call into libflip_dist.so's flip_dist_substep, which makes the same calls from C")
     ap.add_argument("--warm-start", action="store_true",
                     help="flip_set_warm_start 1: a solve starts from the previous substep's solution instead of zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -381,9 +384,14 @@ def main():
             step = NativeDistributedSubstep(ctx, layout, comm, device=local, tol=args.tol, max_iter=args.max_iter, precond=precond,
                                             overlap=overlap, transport=TorchTransport(comm, local) if rehearse and world > 1 else "rccl",
                                             force_slab=world == 1, **extra)
-    else:
+    elif args.python_driver or args.sequential_solves or args.hot_path_only:
         step = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=precond,
                            concurrent_solves=not args.sequential_solves, **extra)
+    else:
+        # one context: flip_dist_substep makes the calls of FlipSubstep.step from C (flip_solve_pair for the two solves)
+        from fluidsimulation_amd.dist_native import NativeDistributedSubstep
+        step = NativeDistributedSubstep(ctx, layout, Comm(), device=local, tol=args.tol, max_iter=args.max_iter, precond=precond,
+                                        overlap=0, transport="rccl", force_slab=False, **extra)
 
     def barrier():
         ctx.synchronize()

@@ -594,10 +594,44 @@ __global__ void k_warm_mask(long long B, const double *__restrict__ cg_inv, doub
 // high neighbour is the neighbour's low coefficient and every load is unconditional (the arrays are padded
 // and zero off the CG rows): no flags, no branches, all 27 loads of a cell in flight together.
 // SYM = false: CG over all rows of the non-symmetric matrix as the reference runs it (flag-driven).
+// What k_pcg_direction reads of a row before it knows the iteration's scalars: z at the 7 stencil points, the
+// couplings (unless the row is a regular one), the diagonal.  (Which of the two direction buffers holds the old
+// direction depends on the iteration number, so p is read later.)
+struct DirRow {
+    long long c;
+    double z[7];
+    float a[6];
+    double d;
+    bool reg;
+};
+__device__ __forceinline__ DirRow d_dir_load(const PcgArgs &A, long long c) {
+    DirRow r;
+    const double *__restrict__ z = A.z;
+    const long long sy = A.sy, sz = A.sz;
+    r.c = c;
+    r.z[0] = z[c]; r.z[1] = z[c - 1]; r.z[2] = z[c + 1]; r.z[3] = z[c - sy]; r.z[4] = z[c + sy]; r.z[5] = z[c - sz]; r.z[6] = z[c + sz];
+    r.reg = A.reg[c] != 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) r.a[q] = 0.f;
+    if (!r.reg) {
+        r.a[0] = A.cgx[c]; r.a[1] = A.cgx[c + 1]; r.a[2] = A.cgy[c]; r.a[3] = A.cgy[c + sy]; r.a[4] = A.cgz[c]; r.a[5] = A.cgz[c + sz];
+    }
+    r.d = A.cg_diag[c];
+    return r;
+}
+
 template <bool SYM>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_direction(PcgArgs A) {
     __shared__ double scratch[12];
     flip_pcg_scalars *S = A.scal;
+    // The loads of a thread's first row do not depend on the scalars of the iteration: they are issued before the stop
+    // flag and the partial sums are read, so that the two chains of dependent loads (flag -> partials -> sum, and
+    // row count -> row list -> vectors) run side by side instead of one after the other.
+    long long lo, hi;
+    d_row_range(A, lo, hi);
+    DirRow first = DirRow();
+    const bool have_first = SYM && lo + threadIdx.x < hi;
+    if (have_first) first = d_dir_load(A, A.rows[lo + threadIdx.x]);
     if (S->done) return;
     const int it = S->it_a;
     double rr, rz, rinf;
@@ -652,39 +686,36 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_direction(PcgArgs A) {
     const double *__restrict__ pold = (it & 1) ? A.p0 : A.p1;
     double *__restrict__ pnew = (it & 1) ? A.p1 : A.p0;
     const double *__restrict__ z = A.z;
-    long long lo, hi;
-    d_row_range(A, lo, hi);
     double pap = 0.0;
     double jp[6] = { 0, 0, 0, 0, 0, 0 };
     if (SYM) {
-        const long long sy = A.sy, sz = A.sz;
-        const float *__restrict__ cx = A.cgx, *__restrict__ cy = A.cgy, *__restrict__ cz = A.cgz;
-        const double *__restrict__ dg = A.cg_diag;
         const float creg = S->creg;
-#pragma unroll 2
+        // one row ahead: the next row's loads are in flight while this one is combined
+        DirRow cur = first;
         for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
-            const long long c = A.rows[q];
-            const double z0 = z[c], zxm = z[c - 1], zxp = z[c + 1], zym = z[c - sy], zyp = z[c + sy], zzm = z[c - sz],
-                         zzp = z[c + sz];
-            const double p0 = pold[c], pxm = pold[c - 1], pxp = pold[c + 1], pym = pold[c - sy], pyp = pold[c + sy],
-                         pzm = pold[c - sz], pzp = pold[c + sz];
+            DirRow nxt = cur;
+            if (q + FLIP_BLOCK < hi) nxt = d_dir_load(A, A.rows[q + FLIP_BLOCK]);
+            const long long c = cur.c;
+            // which of the two direction buffers holds the old direction depends on the iteration number: p is read here
+            const double p0 = pold[c], pxm = pold[c - 1], pxp = pold[c + 1], pym = pold[c - A.sy], pyp = pold[c + A.sy],
+                         pzm = pold[c - A.sz], pzp = pold[c + A.sz];
             float axm = creg, axp = creg, aym = creg, ayp = creg, azm = creg, azp = creg;
-            if (!A.reg[c]) { axm = cx[c]; axp = cx[c + 1]; aym = cy[c]; ayp = cy[c + sy]; azm = cz[c]; azp = cz[c + sz]; }
-            const double d = dg[c];
-            const double pc = z0 + beta * p0;
-            double acc = (double)axm * (zxm + beta * pxm);
-            acc += (double)axp * (zxp + beta * pxp);
-            acc += (double)aym * (zym + beta * pym);
-            acc += (double)ayp * (zyp + beta * pyp);
-            acc += (double)azm * (zzm + beta * pzm);
-            acc += (double)azp * (zzp + beta * pzp);
-            const double s = d * pc - A.s2 * acc;
+            if (!cur.reg) { axm = cur.a[0]; axp = cur.a[1]; aym = cur.a[2]; ayp = cur.a[3]; azm = cur.a[4]; azp = cur.a[5]; }
+            const double pc = cur.z[0] + beta * p0;
+            double acc = (double)axm * (cur.z[1] + beta * pxm);
+            acc += (double)axp * (cur.z[2] + beta * pxp);
+            acc += (double)aym * (cur.z[3] + beta * pym);
+            acc += (double)ayp * (cur.z[4] + beta * pyp);
+            acc += (double)azm * (cur.z[5] + beta * pzm);
+            acc += (double)azp * (cur.z[6] + beta * pzp);
+            const double s = cur.d * pc - A.s2 * acc;
             pnew[c] = pc;
             A.ap[c] = s;
             pap += pc * s;
             if (A.coupled)
 #pragma unroll
                 for (int a = 0; a < 6; ++a) jp[a] += A.J[a][c] * pc;
+            cur = nxt;
         }
     } else {
         for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
