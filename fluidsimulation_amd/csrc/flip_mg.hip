@@ -100,13 +100,15 @@ __device__ __forceinline__ double d_mg_apply(const MgDev<CT> &L, long long c, co
 // Pre-smoothing, both steps of the smoother from a zero guess in one kernel:
 //   t = C1 D^-1 b  (evaluated on the fly at the 7 stencil points),  out = t + A2 t + C2 D^-1 (b - A t)
 template <class CT>
-__device__ __forceinline__ void d_mg_pre(const MgDev<CT> &L, double *__restrict__ out, long long first, long long stride) {
-    const long long n = *L.n_rows;
+__device__ __forceinline__ void d_mg_pre(const MgDev<CT> &L, double *__restrict__ out, long long first, long long stride, long long n) {
     const CT *__restrict__ inv = L.inv;
     const double *__restrict__ b = d_mg_rhs(L);
+    // the row list is read one step ahead: a row's loads then start without waiting for its index
+    long long c_next = first < n ? L.rows[first] : 0;
 #pragma unroll 2
     for (long long q = first; q < n; q += stride) {
-        const long long c = L.rows[q];
+        const long long c = c_next;
+        if (q + stride < n) c_next = L.rows[q + stride];
         const long long sy = L.sy, sz = L.sz;
         const double bc = b[c], ic = (double)inv[c];
         const double t0 = L.c1 * ic * bc;
@@ -124,8 +126,11 @@ __device__ __forceinline__ void d_mg_pre(const MgDev<CT> &L, double *__restrict_
 }
 template <class CT>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_pre(MgDev<CT> L, const int32_t *done, double *__restrict__ out) {
-    if (done && *done) return;
-    d_mg_pre(L, out, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK);
+    // the stop flag and the row count are independent loads: both are in flight before either is looked at
+    const int stop = done ? *done : 0;
+    const long long n = *L.n_rows;
+    if (stop) return;
+    d_mg_pre(L, out, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK, n);
 }
 
 // Second post-smoothing step: out = in + A2 (in - v) + C2 D^-1 (b - A in), where v = out_old + P xc is the corrected
@@ -146,8 +151,10 @@ template <class CT, bool RZ>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, MgDev<double> C, const int32_t *done,
                                                          const double *__restrict__ in, double *out, double *__restrict__ partial) {
     __shared__ double scratch[4];
-    if (done && *done) return;
+    // the stop flag and the row count are independent loads: both are in flight before either is looked at
+    const int stop = done ? *done : 0;
     const long long n = *L.n_rows;
+    if (stop) return;
     const double *__restrict__ rhs = d_mg_rhs(L);
     double acc = 0.0;
     if (RZ) {
@@ -155,9 +162,11 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, MgDev<dou
         const int per = gridDim.x >> 3;
         const int rank = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
         const long long lo = (n * rank) / gridDim.x, hi = (n * (rank + 1)) / gridDim.x;
+        long long c_next = lo + threadIdx.x < hi ? L.rows[lo + threadIdx.x] : 0;
 #pragma unroll 2
         for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
-            const long long c = L.rows[q];
+            const long long c = c_next;
+            if (q + FLIP_BLOCK < hi) c_next = L.rows[q + FLIP_BLOCK];
             const double b = rhs[c];
             const double v = d_mg_second_step(L, C, c, in, out, b);
             out[c] = v;
@@ -166,9 +175,12 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, MgDev<dou
         acc = d_block_sum(acc, scratch);
         if (threadIdx.x == 0) partial[blockIdx.x] = acc;
     } else {
+        const long long first = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, stride = (long long)gridDim.x * FLIP_BLOCK;
+        long long c_next = first < n ? L.rows[first] : 0;
 #pragma unroll 2
-        for (long long q = (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * FLIP_BLOCK) {
-            const long long c = L.rows[q];
+        for (long long q = first; q < n; q += stride) {
+            const long long c = c_next;
+            if (q + stride < n) c_next = L.rows[q + stride];
             out[c] = d_mg_second_step(L, C, c, in, out, rhs[c]);
         }
     }
@@ -187,13 +199,14 @@ __device__ __forceinline__ void d_mg_smooth(const MgDev<double> &L, const MgDev<
 // added on the fly at the 7 stencil points), out = v + C1 D^-1 (b - A v).
 template <class CT>
 __device__ __forceinline__ void d_mg_post(const MgDev<CT> &F, const MgDev<double> &C, const double *__restrict__ in, double *__restrict__ out,
-                                          long long first, long long stride) {
-    const long long n = *F.n_rows;
+                                          long long first, long long stride, long long n) {
     const double *__restrict__ xc = C.x;
     const double *__restrict__ rhs = d_mg_rhs(F);
+    long long c_next = first < n ? F.rows[first] : 0;
 #pragma unroll 2
     for (long long q = first; q < n; q += stride) {
-        const long long c = F.rows[q];
+        const long long c = c_next;
+        if (q + stride < n) c_next = F.rows[q + stride];
         const unsigned cu = (unsigned)c, tq = cu / (unsigned)F.nx;
         const int i = (int)(cu - tq * (unsigned)F.nx);
         const int k = (int)(tq / (unsigned)F.ny), j = (int)(tq - (unsigned)k * (unsigned)F.ny);
@@ -220,24 +233,28 @@ __device__ __forceinline__ void d_mg_post(const MgDev<CT> &F, const MgDev<double
 template <class CT>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post(MgDev<CT> F, MgDev<double> C, const int32_t *done,
                                                        const double *__restrict__ in, double *__restrict__ out) {
-    if (done && *done) return;
-    d_mg_post(F, C, in, out, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK);
+    const int stop = done ? *done : 0;
+    const long long n = *F.n_rows;
+    if (stop) return;
+    d_mg_post(F, C, in, out, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK, n);
 }
 
 // coarse b = sum over the eight children of (b - A v) on the fine level.  Eight lanes per coarse row, one per
 // child, summed by three exchange steps in a fixed order.
 template <class CT>
 __device__ __forceinline__ void d_mg_restrict(const MgDev<CT> &F, const MgDev<double> &C, const double *__restrict__ v, long long first_thread,
-                                              long long total_threads) {
-    const long long n = *C.n_rows;
+                                              long long total_threads, long long n) {
     const double *__restrict__ rhs = d_mg_rhs(F);
     const int child = threadIdx.x & 7;
     const int di = child & 1, dj = (child >> 1) & 1, dk = child >> 2;
+    long long cc_next = (first_thread >> 3) < n ? C.rows[first_thread >> 3] : 0;
     for (long long q = first_thread >> 3; q < ((n + 31) & ~31LL); q += total_threads >> 3) {
         double s = 0.0;
         long long cc = 0;
+        const long long cc_this = cc_next;
+        if (q + (total_threads >> 3) < n) cc_next = C.rows[q + (total_threads >> 3)];
         if (q < n) {
-            cc = C.rows[q];
+            cc = cc_this;
             const unsigned cu = (unsigned)cc, tq = cu / (unsigned)C.nx;
             const int I = (int)(cu - tq * (unsigned)C.nx);
             const int K = (int)(tq / (unsigned)C.ny), J = (int)(tq - (unsigned)K * (unsigned)C.ny);
@@ -256,8 +273,10 @@ __device__ __forceinline__ void d_mg_restrict(const MgDev<CT> &F, const MgDev<do
 template <class CT>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<double> C, const int32_t *done,
                                                            const double *__restrict__ v) {
-    if (done && *done) return;
-    d_mg_restrict(F, C, v, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK);
+    const int stop = done ? *done : 0;
+    const long long n = *C.n_rows;
+    if (stop) return;
+    d_mg_restrict(F, C, v, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK, n);
 }
 
 // Coarsest level: one workgroup, vectors in LDS (dense over the level's cells, zero-padded so that the

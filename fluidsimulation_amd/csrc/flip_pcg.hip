@@ -803,9 +803,43 @@ struct FusedArgs {
     double c1, a2, c2;            // smoother coefficients
     double *r2;
 };
+// What k_pcg_update_pre reads of a row before it knows the iteration's scalars (see k_pcg_direction): Ap and the float
+// inverse diagonal at the 7 stencil points, the couplings unless the row is a regular one, the float diagonal, x.
+// The residual and the direction alternate between two buffers by iteration parity and are read afterwards.
+struct PreRow {
+    long long c;
+    double ap[7];
+    float inv[7];
+    float a[6];
+    float diag;
+    double x;
+    bool reg;
+};
+__device__ __forceinline__ PreRow d_pre_load(const PcgArgs &A, const FusedArgs &F, long long c) {
+    PreRow r;
+    const double *__restrict__ ap = A.ap;
+    const float *__restrict__ inv = F.inv_f;
+    const long long sy = A.sy, sz = A.sz;
+    r.c = c;
+    r.ap[0] = ap[c]; r.ap[1] = ap[c - 1]; r.ap[2] = ap[c + 1]; r.ap[3] = ap[c - sy]; r.ap[4] = ap[c + sy]; r.ap[5] = ap[c - sz]; r.ap[6] = ap[c + sz];
+    r.inv[0] = inv[c]; r.inv[1] = inv[c - 1]; r.inv[2] = inv[c + 1]; r.inv[3] = inv[c - sy]; r.inv[4] = inv[c + sy]; r.inv[5] = inv[c - sz]; r.inv[6] = inv[c + sz];
+    r.reg = A.reg[c] != 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) r.a[q] = 0.f;
+    if (!r.reg) {
+        r.a[0] = A.cgx[c]; r.a[1] = A.cgx[c + 1]; r.a[2] = A.cgy[c]; r.a[3] = A.cgy[c + sy]; r.a[4] = A.cgz[c]; r.a[5] = A.cgz[c + sz];
+    }
+    r.diag = F.diag_f[c];
+    r.x = A.x[c];
+    return r;
+}
 __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update_pre(PcgArgs A, FusedArgs F) {
     __shared__ double scratch[8];
     flip_pcg_scalars *S = A.scal;
+    long long lo, hi;
+    d_row_range(A, lo, hi);
+    PreRow cur = PreRow();
+    if (lo + threadIdx.x < hi) cur = d_pre_load(A, F, A.rows[lo + threadIdx.x]);
     if (S->done) return;
     const int it = S->it_b;
     const double pap = d_reduce_partials(A.partial + 2 * FLIP_MAX_PCG_BLOCKS, A.nblk, scratch);
@@ -813,37 +847,35 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update_pre(PcgArgs A, FusedA
     const double *__restrict__ p = (it & 1) ? A.p1 : A.p0;
     const double *__restrict__ ro = (it & 1) ? F.r2 : A.r;
     double *__restrict__ rn = (it & 1) ? A.r : F.r2;
-    const double *__restrict__ ap = A.ap;
-    const float *__restrict__ inv = F.inv_f;
-    const float *__restrict__ cx = A.cgx, *__restrict__ cy = A.cgy, *__restrict__ cz = A.cgz;
     const long long sy = A.sy, sz = A.sz;
-    long long lo, hi;
-    d_row_range(A, lo, hi);
     double rr = 0.0, rinf = 0.0;
     const float creg = S->creg;
-#pragma unroll 2
     for (long long q = lo + threadIdx.x; q < hi; q += FLIP_BLOCK) {
-        const long long c = A.rows[q];
-        const double rc = ro[c] - alpha * ap[c];
-        const double rxm = ro[c - 1] - alpha * ap[c - 1], rxp = ro[c + 1] - alpha * ap[c + 1];
-        const double rym = ro[c - sy] - alpha * ap[c - sy], ryp = ro[c + sy] - alpha * ap[c + sy];
-        const double rzm = ro[c - sz] - alpha * ap[c - sz], rzp = ro[c + sz] - alpha * ap[c + sz];
-        const double ic = (double)inv[c];
+        PreRow nxt = cur;
+        if (q + FLIP_BLOCK < hi) nxt = d_pre_load(A, F, A.rows[q + FLIP_BLOCK]);
+        const long long c = cur.c;
+        const double rc = ro[c] - alpha * cur.ap[0];
+        const double rxm = ro[c - 1] - alpha * cur.ap[1], rxp = ro[c + 1] - alpha * cur.ap[2];
+        const double rym = ro[c - sy] - alpha * cur.ap[3], ryp = ro[c + sy] - alpha * cur.ap[4];
+        const double rzm = ro[c - sz] - alpha * cur.ap[5], rzp = ro[c + sz] - alpha * cur.ap[6];
+        const double pc = p[c];
+        const double ic = (double)cur.inv[0];
         const double t0 = F.c1 * ic * rc;
         float axm = creg, axp = creg, aym = creg, ayp = creg, azm = creg, azp = creg;
-        if (!A.reg[c]) { axm = cx[c]; axp = cx[c + 1]; aym = cy[c]; ayp = cy[c + sy]; azm = cz[c]; azp = cz[c + sz]; }
-        double acc = (double)axm * (F.c1 * (double)inv[c - 1] * rxm);
-        acc += (double)axp * (F.c1 * (double)inv[c + 1] * rxp);
-        acc += (double)aym * (F.c1 * (double)inv[c - sy] * rym);
-        acc += (double)ayp * (F.c1 * (double)inv[c + sy] * ryp);
-        acc += (double)azm * (F.c1 * (double)inv[c - sz] * rzm);
-        acc += (double)azp * (F.c1 * (double)inv[c + sz] * rzp);
-        const double At = (double)F.diag_f[c] * t0 - A.s2 * acc;
+        if (!cur.reg) { axm = cur.a[0]; axp = cur.a[1]; aym = cur.a[2]; ayp = cur.a[3]; azm = cur.a[4]; azp = cur.a[5]; }
+        double acc = (double)axm * (F.c1 * (double)cur.inv[1] * rxm);
+        acc += (double)axp * (F.c1 * (double)cur.inv[2] * rxp);
+        acc += (double)aym * (F.c1 * (double)cur.inv[3] * rym);
+        acc += (double)ayp * (F.c1 * (double)cur.inv[4] * ryp);
+        acc += (double)azm * (F.c1 * (double)cur.inv[5] * rzm);
+        acc += (double)azp * (F.c1 * (double)cur.inv[6] * rzp);
+        const double At = (double)cur.diag * t0 - A.s2 * acc;
         A.z[c] = t0 + F.a2 * t0 + F.c2 * ic * (rc - At);
-        A.x[c] = A.x[c] + alpha * p[c];
+        A.x[c] = cur.x + alpha * pc;
         rn[c] = rc;
         rr += rc * rc;
         rinf = fmax(rinf, fabs(rc));
+        cur = nxt;
     }
     d_block_sum_max(rr, rinf, scratch);
     if (threadIdx.x == 0) {
