@@ -19,8 +19,11 @@ N > 1: one process per GPU (this script starts them itself when it is not alread
 z-slab decomposition driven by libflip_dist.so (include/flip_dist.h): CG scalars all-reduced and a few planes per slab
 face exchanged every iteration by RCCL calls enqueued on the context's stream, particles near a face exchanged once per
 step (--python-comm: the same loop driven from Python over torch.distributed).
-  --scaling strong (default): the one 256^3 box cut into N slabs; `value` = substeps of that box per second.
-  --scaling weak: a container N times as long along z, one 256^3-sized slab per rank; `value` = N x substeps/s.
+  --scaling weak (default): a container N times as long along z, one 256^3-sized slab per rank, per-GPU work fixed;
+    `value` = N x substeps/s.  The decomposition is made for this: a slab keeps 8 ghost planes of either neighbour, a
+    fixed cost per rank whatever the slab's thickness.
+  --scaling strong: the one 256^3 box cut into N slabs; `value` = substeps of that box per second.  With 139 planes 8
+    ranks own 17 planes each beside their 16 ghost planes: most of a rank's work is redundant and latency-bound.
   --full-domain: the container spans the whole nominal grid (with --n 512 --ppc 16: the ~1e9-particle dam break).
 """
 import argparse
@@ -72,7 +75,7 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-15)
     ap.add_argument("--max-iter", type=int, default=20000)
     ap.add_argument("--precond", default=os.environ.get("FLIP_BENCH_PRECOND", "mg"), choices=["jacobi", "mg"])
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
                     help="N > 1: one box cut into N slabs (strong) or one box-sized slab per rank of an N times longer container (weak)")
     ap.add_argument("--full-domain", action="store_true", help="container over the whole nominal grid instead of main.cpp's half-width box")
     ap.add_argument("--parallel", default="auto", choices=["auto", "slabs", "replicas"],
@@ -449,6 +452,20 @@ def main():
     pcg_gbs = iters * rows * it_bytes / pcg_s / 1e9 if pcg_s > 0 else 0.0
     spmv_s = sum(s["spmv_seconds"] for s in solves)
     spmv_n = sum(s["spmv_launches"] for s in solves)
+    # binning as the substep meets it: right after a whole substep (which ends with moved particles, the sort stale);
+    # measured first, on the state the run has reached, before anything below touches the particles.  Every rank takes
+    # the steps (a substep of a slab run is collective); rank 0 reports its own time.
+    t_bin = 0.0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        step.step(args.dt)
+        barrier()                     # the substep's own work is done before the clock starts
+        e0.record()
+        ctx.bin_particles(want_outside=False)
+        e1.record()
+        e1.synchronize()
+        t_bin += e0.elapsed_time(e1) * 1e-3 / 3
+    n_local = ctx.particle_count()
     entries, stages = [], {}
     jacobi_iters = None
     if rank == 0:
@@ -472,18 +489,6 @@ def main():
                 stages["coarse_levels"] = stage_entry(t_c, its_per_step, rows * 34, "all launches of the V-cycle below level 0 of one "
                                                       "iteration, run alone (bound by launch and dependent-load latency; beside the other "
                                                       "solve's level-0 kernels they mostly hide)")
-        # binning as the substep meets it: right after a whole substep (which ends with moved particles, the sort stale);
-        # measured first, on the state the run has reached, before anything below touches the particles
-        t_bin = 0.0
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
-            step.step(args.dt)
-            barrier()                     # the substep's own work is done before the clock starts
-            e0.record()
-            ctx.bin_particles(want_outside=False)
-            e1.record()
-            e1.synchronize()
-            t_bin += e0.elapsed_time(e1) * 1e-3 / 3
         stages["binning"] = stage_entry(t_bin, 1, SORT_BYTES_PER_PARTICLE * n_local, "whole stage after a real substep: cell ids, scan, slots, "
                                         "per-row reorder (stable order + half-cell ordered copy), bands, gather work list")
         # particle-side kernels and stages, timed alone on that state; the repeated G2P calls change the particle

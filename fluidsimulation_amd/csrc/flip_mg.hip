@@ -185,16 +185,6 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, MgDev<dou
         }
     }
 }
-__device__ __forceinline__ void d_mg_smooth(const MgDev<double> &L, const MgDev<double> &C, const double *__restrict__ in, double *out,
-                                            long long first, long long stride) {
-    const long long n = *L.n_rows;
-    const double *__restrict__ rhs = L.b;
-    for (long long q = first; q < n; q += stride) {
-        const long long c = L.rows[q];
-        out[c] = d_mg_second_step(L, C, c, in, out, rhs[c]);
-    }
-}
-
 // Coarse correction + first post-smoothing step in one kernel: with v = in + P xc (the parent's value
 // added on the fly at the 7 stencil points), out = v + C1 D^-1 (b - A v).
 template <class CT>

@@ -244,7 +244,6 @@ static ParticlePtrs particle_ptrs(flip_ctx *ctx, int buffer) {
 // record is one cache line access instead of two.
 static inline flip_ppos *packed_pos(flip_ctx *ctx) { return reinterpret_cast<flip_ppos *>(ctx->prec); }
 static inline flip_pvel *packed_vel(flip_ctx *ctx) { return reinterpret_cast<flip_pvel *>(reinterpret_cast<flip_ppos *>(ctx->prec) + 1); }
-static inline size_t subrow_lds_bytes(const flip_ctx *ctx) { return flip_subrow_lds_bytes(ctx->g.nx); }
 
 // Occupancy bands: bit0 = within 1 cell of a particle cell, bit1 = within 2 (Chebyshev distance).
 // Box dilation is separable: one pass per axis.
@@ -725,7 +724,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_gather(GridDims g, int nyb, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-staged form of the gather (the default).  A workgroup owns a tile of 4 x 4 x 4 cells.  The support of the tile
+// LDS-staged form of the gather (flip_set_gather_mode 1; same bits as k_gather, measured slower).  A workgroup owns a tile of 4 x 4 x 4 cells.  The support of the tile
 // is 10 x 10 (z, y) half-cell rows, and within each of them ONE contiguous span of the half-cell order (the half cells
 // 2 i0 - 1 .. 2 i0 + 8 of that sub-row): the workgroup copies those 100 spans into LDS with coalesced 16-byte loads
 // -- every record once per tile instead of once per cell and lane -- as separate arrays x[], y[], z[], vx[], vy[],
