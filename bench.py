@@ -444,7 +444,8 @@ def main():
     solves = [i[k] for i in infos for k in ("divergence", "density") if i[k] is not None]
     rows = solves[0]["cg_rows"]
     iters = sum(s["iterations"] for s in solves)
-    paired = not slabs and not args.sequential_solves
+    # the C driver runs the two solves of a step side by side on one context and over slabs alike; the Python slab driver one after the other
+    paired = not args.sequential_solves and not (slabs and args.python_comm)
     # side by side, the two solves of a step overlap in time: the solver's share of the step is the longer of the two
     pcg_s = sum(max(i[k]["seconds"] for k in ("divergence", "density") if i[k] is not None) for i in infos) if paired \
         else sum(s["seconds"] for s in solves)

@@ -64,7 +64,7 @@ EXPORTS = [
     "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_fluid_levelset_from_particles", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
     "flip_update_prev", "flip_update_diff", "flip_swap_velocity_buffers", "flip_swap_valid_masks", "flip_velocity_max", "flip_velocity_max_static", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_redistribute_overdense", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
-    "flip_update_particles", "flip_set_system_options", "flip_set_warm_start", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_project_velocity",
+    "flip_update_particles", "flip_set_system_options", "flip_set_warm_start", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_pair_begin", "flip_pair_select", "flip_pair_end", "flip_project_velocity",
     "flip_project_displacement", "flip_set_slab", "flip_solid_coupling_partial", "flip_solid_velocity_apply", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
     "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish", "flip_set_slab_overlap",
     "flip_pcg_dist_precondition", "flip_pcg_dist_combine", "flip_particles_reserve", "flip_particles_pack",
@@ -128,6 +128,9 @@ def load_library(path: str = LIB_PATH):
         "flip_build_system": (C.c_int, [vp, C.c_int, f32]),
         "flip_set_system_options": (C.c_int, [vp, C.c_int, C.c_int]),
         "flip_set_warm_start": (C.c_int, [vp, C.c_int]),
+        "flip_pair_begin": (C.c_int, [vp]),
+        "flip_pair_select": (C.c_int, [vp, C.c_int]),
+        "flip_pair_end": (C.c_int, [vp]),
         "flip_update_particles": (C.c_int, [vp, f32, f32, C.c_int, C.c_int]),
         "flip_system_download": (C.c_int, [vp, vp, vp, vp]),
         "flip_pcg_solve": (C.c_int, [vp, f64, i32, C.c_int, P(PcgInfo)]),

@@ -105,6 +105,10 @@ void flip_free_system(flip_ctx *c) {
     c->events.clear();
     for (hipGraphExec_t &e : c->batch_exec)
         if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
+    // the slab solve's arrays of this set
+    if (c->mg_cz) { (void)hipFree(c->mg_cz - c->pad); c->mg_cz = nullptr; }
+    dfree(c->dist_sums); dfree(c->mg_rows); dfree(c->dist_recv[0]); dfree(c->dist_recv[1]);
+    if (c->dist_rw) { (void)hipFree(c->dist_rw - c->pad); c->dist_rw = nullptr; }
 }
 
 void flip_swap_systems(flip_ctx *c) {
@@ -123,6 +127,10 @@ void flip_swap_systems(flip_ctx *c) {
     std::swap(c->mg_diag_f, o.mg_diag_f); std::swap(c->mg_inv_f, o.mg_inv_f);
     for (int q = 0; q < 2; ++q) { std::swap(c->batch_exec[q], o.batch_exec[q]); std::swap(c->batch_key[q], o.batch_key[q]); }
     std::swap(c->cg_scan, o.cg_scan); std::swap(c->scan_tmp, o.scan_tmp); std::swap(c->scan_tmp_len, o.scan_tmp_len);
+    std::swap(c->mg_cz, o.mg_cz); std::swap(c->dist_sums, o.dist_sums); std::swap(c->dist_active, o.dist_active);
+    std::swap(c->dist_mg, o.dist_mg); std::swap(c->dist_max_iter, o.dist_max_iter); std::swap(c->dist_prof, o.dist_prof);
+    std::swap(c->mg_rows, o.mg_rows); std::swap(c->dist_recv[0], o.dist_recv[0]); std::swap(c->dist_recv[1], o.dist_recv[1]);
+    std::swap(c->dist_recv_planes, o.dist_recv_planes); std::swap(c->dist_rw, o.dist_rw);
 }
 
 extern "C" void flip_ctx_destroy(flip_ctx *c) {
@@ -153,9 +161,6 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
     dfree(c->density); dfree(c->active); dfree(c->active_back); dfree(c->label); dfree(c->band);
     dfree(c->seed); dfree(c->tmp_u8); dfree(c->row_index);
     dfree(c->cg_scan); dfree(c->other.cg_scan); dfree(c->other.scan_tmp);
-    if (c->mg_cz) (void)hipFree(c->mg_cz - c->pad);
-    dfree(c->dist_sums); dfree(c->mg_rows); dfree(c->dist_recv[0]); dfree(c->dist_recv[1]);
-    if (c->dist_rw) (void)hipFree(c->dist_rw - c->pad);
     dfree(c->d_vmax);
     dfree(c->gather_stats); dfree(c->tile_scan); dfree(c->tile_list); dfree(c->slot_scan); dfree(c->slot_list); dfree(c->gather_claim);
     delete c;

@@ -12,26 +12,30 @@
 namespace {
 std::string g_create_error;
 
+// Two communicators over the same ranks: the two solves of a substep run side by side on two streams, and operations on
+// one communicator are serialised whatever stream they are enqueued on.  `channel` says which one the next call uses.
 struct RcclState {
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm[2] = { nullptr, nullptr };
+    int channel = 0;
     int rank = 0, world = 1;
 };
 
 int rccl_all_reduce(void *user, double *buf, int64_t count, int op, void *stream) {
     RcclState *s = static_cast<RcclState *>(user);
-    const ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count, ncclDouble, op == FLIP_DIST_MAX ? ncclMax : ncclSum, s->comm, (hipStream_t)stream);
+    const ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count, ncclDouble, op == FLIP_DIST_MAX ? ncclMax : ncclSum, s->comm[s->channel], (hipStream_t)stream);
     return r == ncclSuccess ? 0 : (int)r;
 }
 int rccl_exchange(void *user, const void *send_lo, int64_t send_lo_bytes, void *recv_lo, int64_t recv_lo_bytes, const void *send_hi,
                   int64_t send_hi_bytes, void *recv_hi, int64_t recv_hi_bytes, void *stream) {
     RcclState *s = static_cast<RcclState *>(user);
     hipStream_t st = (hipStream_t)stream;
+    ncclComm_t comm = s->comm[s->channel];
     ncclResult_t r = ncclGroupStart();
     // grouped: the four transfers of a face pair progress together, no ordering between ranks can deadlock them
-    if (r == ncclSuccess && s->rank > 0 && send_lo) r = ncclSend(send_lo, (size_t)send_lo_bytes, ncclChar, s->rank - 1, s->comm, st);
-    if (r == ncclSuccess && s->rank > 0 && recv_lo) r = ncclRecv(recv_lo, (size_t)recv_lo_bytes, ncclChar, s->rank - 1, s->comm, st);
-    if (r == ncclSuccess && s->rank < s->world - 1 && send_hi) r = ncclSend(send_hi, (size_t)send_hi_bytes, ncclChar, s->rank + 1, s->comm, st);
-    if (r == ncclSuccess && s->rank < s->world - 1 && recv_hi) r = ncclRecv(recv_hi, (size_t)recv_hi_bytes, ncclChar, s->rank + 1, s->comm, st);
+    if (r == ncclSuccess && s->rank > 0 && send_lo) r = ncclSend(send_lo, (size_t)send_lo_bytes, ncclChar, s->rank - 1, comm, st);
+    if (r == ncclSuccess && s->rank > 0 && recv_lo) r = ncclRecv(recv_lo, (size_t)recv_lo_bytes, ncclChar, s->rank - 1, comm, st);
+    if (r == ncclSuccess && s->rank < s->world - 1 && send_hi) r = ncclSend(send_hi, (size_t)send_hi_bytes, ncclChar, s->rank + 1, comm, st);
+    if (r == ncclSuccess && s->rank < s->world - 1 && recv_hi) r = ncclRecv(recv_hi, (size_t)recv_hi_bytes, ncclChar, s->rank + 1, comm, st);
     const ncclResult_t e = ncclGroupEnd();
     if (r == ncclSuccess) r = e;
     return r == ncclSuccess ? 0 : (int)r;
@@ -42,6 +46,7 @@ struct flip_dist {
     flip_ctx *ctx = nullptr;
     int rank = 0, world = 1;
     bool slab = false;           // the context is in slab mode (world > 1 or forced)
+    bool pair_solves = true;     // the two slab solves of a substep side by side (FLIP_DIST_SEQUENTIAL_SOLVES: one after the other)
     int32_t ghost = 0, overlap = 0;
     int32_t k0 = 0, k1 = 0;      // owned planes in the context's own plane numbers
     int32_t g_lo = 0, g_hi = 0;  // ghost planes of this box toward the lower / upper neighbour
@@ -126,28 +131,69 @@ int precondition_and_sums(flip_dist *d, const SolveBuffers &b) {
     return 0;
 }
 
-int slab_cg(flip_dist *d, double tol, int32_t max_iter, int precond, flip_pcg_info *info) {
+// One slab solve as the driver sees it: the buffers of the system it works on, the stream that system's kernels are
+// enqueued on and the communicator its collectives use.  `select` makes that system the context's active one (only
+// needed when two solves are in progress, flip_pair_select).
+struct SlabSolve {
+    int slot = -1;            // -1: the context's only system; 0 / 1: a system of a pair
     SolveBuffers b;
-    if (solve_buffers(d, b)) return 1;
-    DIST_FLIP(flip_pcg_dist_begin(d->ctx, tol, max_iter, precond));
-    if (precondition_and_sums(d, b)) return 1;
     int32_t done = 0, it = 0;
-    while (!done) {
-        // the stop flag is a function of all-reduced values only: every rank leaves after the same batch
-        for (int q = 0; q < 8; ++q) {
-            DIST_FLIP(flip_pcg_dist_direction(d->ctx));
-            DIST_TR(d->tr.all_reduce(d->tr.user, b.sums, 16, FLIP_DIST_SUM, d->stream));
-            DIST_FLIP(flip_pcg_dist_update(d->ctx));
-            if (precondition_and_sums(d, b)) return 1;
-        }
-        DIST_FLIP(flip_pcg_dist_status(d->ctx, &done, &it));
+};
+int slab_select(flip_dist *d, SlabSolve &s) {
+    if (s.slot >= 0) {
+        DIST_FLIP(flip_pair_select(d->ctx, s.slot));
+        void *st = nullptr;
+        DIST_FLIP(flip_get_stream(d->ctx, &st, nullptr));
+        d->stream = (hipStream_t)st;
+        d->rccl.channel = s.slot;
     }
+    return 0;
+}
+int slab_begin(flip_dist *d, SlabSolve &s, double tol, int32_t max_iter, int precond) {
+    if (slab_select(d, s)) return 1;
+    if (solve_buffers(d, s.b)) return 1;
+    DIST_FLIP(flip_pcg_dist_begin(d->ctx, tol, max_iter, precond));
+    return precondition_and_sums(d, s.b);
+}
+int slab_iteration(flip_dist *d, SlabSolve &s) {
+    if (slab_select(d, s)) return 1;
+    DIST_FLIP(flip_pcg_dist_direction(d->ctx));
+    DIST_TR(d->tr.all_reduce(d->tr.user, s.b.sums, 16, FLIP_DIST_SUM, d->stream));
+    DIST_FLIP(flip_pcg_dist_update(d->ctx));
+    return precondition_and_sums(d, s.b);
+}
+int slab_finish(flip_dist *d, SlabSolve &s, flip_pcg_info *info) {
+    if (slab_select(d, s)) return 1;
     // every ghost plane of the solution from the neighbour that owns it
     const int64_t P = d->plane, k0 = d->k0, k1 = d->k1;
-    if (exchange_planes(d, b.x + k0 * P, d->g_of_lower, b.x + (k0 - d->g_lo) * P, d->g_lo, b.x + (k1 - d->g_of_upper) * P, d->g_of_upper,
-                        b.x + k1 * P, d->g_hi))
+    if (exchange_planes(d, s.b.x + k0 * P, d->g_of_lower, s.b.x + (k0 - d->g_lo) * P, d->g_lo, s.b.x + (k1 - d->g_of_upper) * P, d->g_of_upper,
+                        s.b.x + k1 * P, d->g_hi))
         return 1;
     DIST_FLIP(flip_pcg_dist_finish(d->ctx, info));
+    return 0;
+}
+
+int slab_cg(flip_dist *d, double tol, int32_t max_iter, int precond, flip_pcg_info *info) {
+    SlabSolve s;
+    if (slab_begin(d, s, tol, max_iter, precond)) return 1;
+    while (!s.done) {
+        // the stop flag is a function of all-reduced values only: every rank leaves after the same batch
+        for (int q = 0; q < 8; ++q)
+            if (slab_iteration(d, s)) return 1;
+        DIST_FLIP(flip_pcg_dist_status(d->ctx, &s.done, &s.it));
+    }
+    return slab_finish(d, s, info);
+}
+
+// The rigid-body agreement of flip_dist_solve (see there) for the active system.
+int agree_no_dependent_coupling(flip_dist *d) {
+    int32_t coupled = 0;
+    DIST_FLIP(flip_system_dependent_coupled(d->ctx, &coupled));
+    double any = coupled > 0 ? 1.0 : 0.0;
+    if (flip_dist_all_reduce(d, &any, 1, FLIP_DIST_MAX)) return 1;
+    if (any > 0.0)
+        return fail(d, "flip_dist_solve: the rigid body touches dependent rows (cells with phi_fluid >= 0 that carry a pressure row) on some "
+                       "rank; the slab solver needs the eliminated system, which such rows rule out");
     return 0;
 }
 
@@ -172,6 +218,7 @@ int create_common(flip_ctx *ctx, int rank, int world, const int32_t *starts, int
     d = new flip_dist();
     d->ctx = ctx; d->rank = rank; d->world = world; d->ghost = ghost;
     d->slab = world > 1 || (flags & FLIP_DIST_FORCE_SLAB);
+    d->pair_solves = !(flags & FLIP_DIST_SEQUENTIAL_SOLVES);
     d->overlap = (world > 1) ? overlap : 0;
     d->plane = (int64_t)g.nx * g.ny;
     if (world > 1) {
@@ -229,7 +276,7 @@ extern "C" int flip_dist_create(flip_ctx *ctx, int rank, int world, const void *
     flip_dist *d = *out;
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
-    const ncclResult_t r = ncclCommInitRank(&d->rccl.comm, world, id, rank);
+    const ncclResult_t r = ncclCommInitRank(&d->rccl.comm[0], world, id, rank);
     if (r != ncclSuccess) {
         const std::string msg = std::string("ncclCommInitRank: ") + ncclGetErrorString(r);
         flip_dist_destroy(d);
@@ -237,6 +284,10 @@ extern "C" int flip_dist_create(flip_ctx *ctx, int rank, int world, const void *
         return fail(nullptr, msg);
     }
     d->own_comm = true;
+    // the second communicator, for the solve that runs beside the first one (same ranks, same order)
+    if (ncclCommSplit(d->rccl.comm[0], 0, rank, &d->rccl.comm[1], nullptr) != ncclSuccess || !d->rccl.comm[1]) {
+        d->rccl.comm[1] = d->rccl.comm[0];   // one communicator serves both: its operations then run one after the other
+    }
     d->rccl.rank = rank; d->rccl.world = world;
     d->tr.user = &d->rccl;
     d->tr.all_reduce = rccl_all_reduce;
@@ -256,7 +307,10 @@ extern "C" void flip_dist_destroy(flip_dist *d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->stream || d->ctx) (void)hipStreamSynchronize(d->stream);
-    if (d->own_comm && d->rccl.comm) (void)ncclCommDestroy(d->rccl.comm);
+    if (d->own_comm) {
+        if (d->rccl.comm[1] && d->rccl.comm[1] != d->rccl.comm[0]) (void)ncclCommDestroy(d->rccl.comm[1]);
+        if (d->rccl.comm[0]) (void)ncclCommDestroy(d->rccl.comm[0]);
+    }
     void *bufs[6] = { d->send_lo, d->send_hi, d->recv_lo, d->recv_hi, d->counts_dev, d->small_dev };
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -287,14 +341,56 @@ extern "C" int flip_dist_solve(flip_dist *d, int kind, float dt, double tol, int
     // The slab solver works on the eliminated system.  A rigid-body row that is also a dependent row (a free-surface cell
     // next to the body) rules that out, and whether one exists is a property of all slabs together: agree before the
     // first collective of the solve, so that every rank takes the same way out.
-    int32_t coupled = 0;
-    DIST_FLIP(flip_system_dependent_coupled(d->ctx, &coupled));
-    double any = coupled > 0 ? 1.0 : 0.0;
-    if (flip_dist_all_reduce(d, &any, 1, FLIP_DIST_MAX)) return 1;
-    if (any > 0.0)
-        return fail(d, "flip_dist_solve: the rigid body touches dependent rows (cells with phi_fluid >= 0 that carry a pressure row) on some "
-                       "rank; the slab solver needs the eliminated system, which such rows rule out");
+    if (agree_no_dependent_coupling(d)) return 1;
     return slab_cg(d, tol, max_iter, precond, info);
+}
+
+extern "C" int flip_dist_solve_pair(flip_dist *d, float dt, double tol, int32_t max_iter, int precond, flip_pcg_info *info_divergence,
+                                    flip_pcg_info *info_density) {
+    if (!d || !info_divergence || !info_density) return fail(d, "flip_dist_solve_pair: null argument");
+    if (!d->slab) {
+        DIST_FLIP(flip_solve_pair(d->ctx, dt, tol, max_iter, precond, info_divergence, info_density));
+        return 0;
+    }
+    // Both systems are assembled first (the density system needs nothing the divergence solve produces), each into a
+    // system set and on a stream of its own; then the two slab solves advance in turn, an iteration of one, an iteration
+    // of the other: nothing orders the two streams against each other, so the all-reduces and plane exchanges of one
+    // solve travel while the kernels of the other run.  Every rank issues the same calls in the same order.
+    hipStream_t main_stream = d->stream;
+    DIST_FLIP(flip_pair_begin(d->ctx));
+    SlabSolve s[2];
+    s[0].slot = 0; s[1].slot = 1;
+    int rc = 0;
+    auto leave = [&](int code) {
+        const std::string text = d->err;
+        (void)flip_pair_end(d->ctx);
+        d->stream = main_stream;
+        d->rccl.channel = 0;
+        if (code) d->err = text;
+        return code;
+    };
+    // slot 0: the divergence system, which stays the active one afterwards; slot 1: the density system
+    if (slab_select(d, s[1])) return leave(1);
+    if (flip_build_system(d->ctx, FLIP_SOLVE_DENSITY, dt) != 0) return leave(fail_ctx(d, "flip_build_system"));
+    if (slab_select(d, s[0])) return leave(1);
+    if (flip_build_system(d->ctx, FLIP_SOLVE_DIVERGENCE, dt) != 0) return leave(fail_ctx(d, "flip_build_system"));
+    if (agree_no_dependent_coupling(d)) return leave(1);
+    for (int q = 1; q >= 0 && !rc; --q) rc = slab_begin(d, s[q], tol, max_iter, precond);
+    if (rc) return leave(1);
+    while (!s[0].done || !s[1].done) {
+        for (int b = 0; b < 8 && !rc; ++b)
+            for (int q = 0; q < 2 && !rc; ++q)
+                if (!s[q].done) rc = slab_iteration(d, s[q]);
+        for (int q = 0; q < 2 && !rc; ++q)
+            if (!s[q].done) {
+                rc = slab_select(d, s[q]);
+                if (!rc && flip_pcg_dist_status(d->ctx, &s[q].done, &s[q].it) != 0) rc = fail_ctx(d, "flip_pcg_dist_status");
+            }
+        if (rc) return leave(1);
+    }
+    if (slab_finish(d, s[1], info_density)) return leave(1);
+    if (slab_finish(d, s[0], info_divergence)) return leave(1);
+    return leave(0);
 }
 
 extern "C" int flip_dist_exchange_particles(flip_dist *d, int64_t sent[2], int64_t received[2]) {
@@ -355,10 +451,17 @@ extern "C" int flip_dist_substep(flip_dist *d, float dt, const flip_dist_step_op
     DIST_FLIP(flip_index_cells(c, nullptr));                  // :486
     DIST_FLIP(flip_face_fractions(c));                        // :488
     DIST_FLIP(flip_density(c, nullptr));                      // :491
-    if (!d->slab && o->density_projection) {
-        // one context: both solves side by side, exactly the single-context substep
-        DIST_FLIP(flip_solve_pair(c, dt, o->tol, o->max_iter, o->precond, &info[0], &info[1]));   // :505 and :521
+    if (o->density_projection && (!d->slab || d->pair_solves)) {
+        // both solves side by side (:505 and :521): on one context flip_solve_pair, over slabs the two slab solves in turn
+        if (flip_dist_solve_pair(d, dt, o->tol, o->max_iter, o->precond, &info[0], &info[1])) return 1;
         DIST_FLIP(flip_project_velocity(c, dt));              // :507
+        if (body && d->slab) {
+            // V += dt Minv (J p), J p summed over every slab's rows (:1095-1100)
+            double jp[6];
+            DIST_FLIP(flip_solid_coupling_partial(c, jp));
+            if (flip_dist_all_reduce(d, jp, 6, FLIP_DIST_SUM)) return 1;
+            DIST_FLIP(flip_solid_velocity_apply(c, dt, jp));
+        }
         DIST_FLIP(flip_select_system(c, FLIP_SOLVE_DENSITY));
         DIST_FLIP(flip_project_displacement(c, dt));          // :523
         DIST_FLIP(flip_select_system(c, FLIP_SOLVE_DIVERGENCE));

@@ -102,6 +102,16 @@ struct flip_system_set {
     uint64_t batch_key[2] = { 0, 0 };
     int32_t *cg_scan = nullptr, *scan_tmp = nullptr;   // scan scratch: the two systems are set up side by side
     int64_t scan_tmp_len = 0;
+    // the slab solve's arrays and state (see flip_ctx): two slab solves can be in progress side by side (flip_pair_*)
+    float *mg_cz = nullptr;
+    double *dist_sums = nullptr;
+    bool dist_active = false, dist_mg = false;
+    int32_t dist_max_iter = 0;
+    int dist_prof = 0;
+    int32_t *mg_rows = nullptr;
+    double *dist_recv[2] = {};
+    int32_t dist_recv_planes = 0;
+    double *dist_rw = nullptr;
     bool allocated = false;
 };
 
@@ -240,8 +250,13 @@ struct flip_ctx {
     int32_t slab_overlap = 0;
     int32_t *mg_rows = nullptr;     // [B] rows of planes [slab_k0 - overlap, slab_k1 + overlap); count in d_counts[7]
     double *dist_recv[2] = {};      // [(overlap + 1) planes] corrections received from the lower / upper neighbour
+    int32_t dist_recv_planes = 0;   // the overlap dist_recv was sized for
     bool slab_weighted = false;     // partition-of-unity weights across the overlap (see flip_set_slab_overlap)
     double *dist_rw = nullptr;      // weighted copy of the residual, the V-cycle's right-hand side when slab_weighted
+    // flip_pair_begin .. flip_pair_end: the caller works on the two system sets in turn, each on a stream of its own
+    bool pair_on = false;
+    int pair_slot = 0;              // which set is the active one (0: the set that was active at flip_pair_begin)
+    hipStream_t pair_main_stream = nullptr;   // the context's stream while ctx->stream points at a pair stream
 };
 
 int flip_default_gather_mode();            // FLIP_GATHER_TILE

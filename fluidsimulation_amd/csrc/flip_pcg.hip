@@ -220,13 +220,10 @@ __global__ void k_mark_regular(const int32_t *__restrict__ rows, const int32_t *
     }
 }
 
-extern "C" int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1) {
-    FLIP_REQUIRE(ctx, "null context");
-    FLIP_REQUIRE(k0 >= 0 && k1 > k0 && k1 <= ctx->g.nz, "flip_set_slab: need 0 <= k0 < k1 <= nz");
-    FLIP_CHECK(hipSetDevice(ctx->device));
-    ctx->slab_on = !(k0 == 0 && k1 == ctx->g.nz);
-    ctx->slab_k0 = k0;
-    ctx->slab_k1 = k1;
+// The slab solve's arrays of the ACTIVE system set, for the slab and overlap the context is set to (both sets need them
+// when two slab solves run side by side, flip_pair_begin).
+static int slab_alloc_state(flip_ctx *ctx) {
+    const size_t plane = (size_t)ctx->g.nx * ctx->g.ny;
     if (ctx->slab_on && !ctx->mg_cz) {
         // padded like the other coupling arrays: the stencil kernels read one plane beyond either end
         float *base = nullptr;
@@ -238,25 +235,11 @@ extern "C" int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1) {
         FLIP_CHECK(hipMalloc((void **)&ctx->dist_sums, 16 * sizeof(double)));
         FLIP_CHECK(flip_zero_new(ctx->dist_sums, 16 * sizeof(double)));
     }
-    ctx->slab_overlap = 0;
-    ctx->sys_kind = -1; // a system assembled under another ownership is stale
-    return 0;
-}
-
-extern "C" int flip_set_slab_overlap(flip_ctx *ctx, int32_t planes) {
-    FLIP_REQUIRE(ctx, "null context");
-    FLIP_REQUIRE(ctx->dist_sums, "flip_set_slab_overlap: call flip_set_slab first");
-    FLIP_REQUIRE(planes >= 0, "flip_set_slab_overlap: the overlap cannot be negative");
-    FLIP_REQUIRE(!ctx->dist_active, "flip_set_slab_overlap: a solve is in progress");
-    // a face with a neighbour behind it has ghost planes; the overlap must fit into them
-    FLIP_REQUIRE(ctx->slab_k0 == 0 || planes <= ctx->slab_k0, "flip_set_slab_overlap: more planes than the lower ghost zone holds");
-    FLIP_REQUIRE(ctx->slab_k1 == ctx->g.nz || planes <= ctx->g.nz - ctx->slab_k1,
-                 "flip_set_slab_overlap: more planes than the upper ghost zone holds");
-    FLIP_CHECK(hipSetDevice(ctx->device));
-    const size_t plane = (size_t)ctx->g.nx * ctx->g.ny;
-    if (planes != ctx->slab_overlap) {
+    const int32_t planes = ctx->slab_overlap;
+    if (planes != ctx->dist_recv_planes) {
         for (int s = 0; s < 2; ++s)
             if (ctx->dist_recv[s]) { FLIP_CHECK(hipFree(ctx->dist_recv[s])); ctx->dist_recv[s] = nullptr; }
+        ctx->dist_recv_planes = 0;
     }
     if (planes > 0 && ctx->slab_on) {
         if (!ctx->mg_rows) FLIP_CHECK(hipMalloc((void **)&ctx->mg_rows, (size_t)ctx->B * 4));
@@ -265,12 +248,7 @@ extern "C" int flip_set_slab_overlap(flip_ctx *ctx, int32_t planes) {
                 FLIP_CHECK(hipMalloc((void **)&ctx->dist_recv[s], (size_t)(planes + 1) * plane * 8));
                 FLIP_CHECK(flip_zero_new(ctx->dist_recv[s], (size_t)(planes + 1) * plane * 8));
             }
-    }
-    ctx->slab_overlap = ctx->slab_on ? planes : 0;
-    ctx->slab_weighted = false;
-    if (ctx->slab_overlap > 0) {
-        const char *e = getenv("FLIP_SLAB_WEIGHTED");
-        ctx->slab_weighted = !(e && atoi(e) == 0);
+        ctx->dist_recv_planes = planes;
     }
     if (ctx->slab_weighted && !ctx->dist_rw) {
         double *base = nullptr;
@@ -278,7 +256,44 @@ extern "C" int flip_set_slab_overlap(flip_ctx *ctx, int32_t planes) {
         FLIP_CHECK(flip_zero_new(base, (size_t)(ctx->B + 2 * ctx->pad) * sizeof(double)));
         ctx->dist_rw = base + ctx->pad;
     }
+    return 0;
+}
+
+extern "C" int flip_set_slab(flip_ctx *ctx, int32_t k0, int32_t k1) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(k0 >= 0 && k1 > k0 && k1 <= ctx->g.nz, "flip_set_slab: need 0 <= k0 < k1 <= nz");
+    FLIP_REQUIRE(!ctx->pair_on, "flip_set_slab: not between flip_pair_begin and flip_pair_end");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    ctx->slab_on = !(k0 == 0 && k1 == ctx->g.nz);
+    ctx->slab_k0 = k0;
+    ctx->slab_k1 = k1;
+    ctx->slab_overlap = 0;
+    ctx->slab_weighted = false;
+    if (int rc = slab_alloc_state(ctx)) return rc;
+    ctx->sys_kind = -1; // a system assembled under another ownership is stale
+    ctx->other.sys_kind = -1;
+    return 0;
+}
+
+extern "C" int flip_set_slab_overlap(flip_ctx *ctx, int32_t planes) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(ctx->dist_sums, "flip_set_slab_overlap: call flip_set_slab first");
+    FLIP_REQUIRE(planes >= 0, "flip_set_slab_overlap: the overlap cannot be negative");
+    FLIP_REQUIRE(!ctx->dist_active && !ctx->pair_on, "flip_set_slab_overlap: a solve is in progress");
+    // a face with a neighbour behind it has ghost planes; the overlap must fit into them
+    FLIP_REQUIRE(ctx->slab_k0 == 0 || planes <= ctx->slab_k0, "flip_set_slab_overlap: more planes than the lower ghost zone holds");
+    FLIP_REQUIRE(ctx->slab_k1 == ctx->g.nz || planes <= ctx->g.nz - ctx->slab_k1,
+                 "flip_set_slab_overlap: more planes than the upper ghost zone holds");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    ctx->slab_overlap = ctx->slab_on ? planes : 0;
+    ctx->slab_weighted = false;
+    if (ctx->slab_overlap > 0) {
+        const char *e = getenv("FLIP_SLAB_WEIGHTED");
+        ctx->slab_weighted = !(e && atoi(e) == 0);
+    }
+    if (int rc = slab_alloc_state(ctx)) return rc;
     ctx->sys_kind = -1;
+    ctx->other.sys_kind = -1;
     return 0;
 }
 
@@ -1166,6 +1181,7 @@ static int pcg_report(flip_ctx *ctx, const PcgRun &run, const PcgTail &t, flip_p
 
 extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int precond, flip_pcg_info *info) {
     FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(!ctx->pair_on, "flip_pcg_solve: not between flip_pair_begin and flip_pair_end");
     FLIP_CHECK(hipSetDevice(ctx->device));
     PcgRun run;
     if (int rc = pcg_prepare(ctx, tol, max_iter, precond, run, "flip_pcg_solve")) return rc;
@@ -1202,27 +1218,33 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
 // iterated side by side on two streams: the latency-bound coarse levels of one V-cycle run under the bandwidth-bound
 // fine level of the other.  Each solve performs exactly the operations flip_build_system + flip_pcg_solve would.
 // Afterwards the divergence system is the active one; flip_select_system switches between the two for the projections.
+// The arrays of the second system set (allocated on first use).
+static int ensure_other_set(flip_ctx *ctx) {
+    if (ctx->other.allocated) return 0;
+    flip_swap_systems(ctx);
+    int rc = flip_alloc_system(ctx);
+    if (!rc && hipMalloc((void **)&ctx->cg_scan, (size_t)(ctx->B + 1) * 4) != hipSuccess)
+        rc = flip_fail(ctx, "hipMalloc of the second system's scan scratch", __FILE__, __LINE__);
+    if (rc) {
+        // nothing of a half-allocated set may survive: the next call would allocate over its pointers
+        flip_free_system(ctx);
+        if (ctx->cg_scan) { (void)hipFree(ctx->cg_scan); ctx->cg_scan = nullptr; }
+    }
+    flip_swap_systems(ctx);
+    if (rc) return rc;
+    ctx->other.allocated = true;
+    return 0;
+}
+
 extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_iter, int precond, flip_pcg_info *info_divergence,
                                flip_pcg_info *info_density) {
     FLIP_REQUIRE(ctx, "null context");
     FLIP_REQUIRE(!ctx->slab_on, "flip_solve_pair: not available on a slab context");
+    FLIP_REQUIRE(!ctx->pair_on, "flip_solve_pair: not between flip_pair_begin and flip_pair_end");
     FLIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t main_stream = ctx->stream;
     if (int rc0 = pair_streams(ctx)) return rc0;
-    if (!ctx->other.allocated) {
-        flip_swap_systems(ctx);
-        int rc = flip_alloc_system(ctx);
-        if (!rc && hipMalloc((void **)&ctx->cg_scan, (size_t)(ctx->B + 1) * 4) != hipSuccess)
-            rc = flip_fail(ctx, "hipMalloc of the second system's scan scratch", __FILE__, __LINE__);
-        if (rc) {
-            // nothing of a half-allocated set may survive: the next call would allocate over its pointers
-            flip_free_system(ctx);
-            if (ctx->cg_scan) { (void)hipFree(ctx->cg_scan); ctx->cg_scan = nullptr; }
-        }
-        flip_swap_systems(ctx);
-        if (rc) return rc;
-        ctx->other.allocated = true;
-    }
+    if (int rc0 = ensure_other_set(ctx)) return rc0;
     // The density system lives in the other set, the divergence system in the active one.  Assembly and solver set-up of
     // each (coarse operators, row lists: several dozen small launches) already run on the solve's own stream, side by
     // side with the other's; every scratch array they use belongs to the system set.
@@ -1330,6 +1352,58 @@ extern "C" int flip_select_system(flip_ctx *ctx, int kind) {
     if (ctx->sys_kind == kind) return 0;
     FLIP_REQUIRE(ctx->other.allocated && ctx->other.sys_kind == kind, "flip_select_system: no assembled system of this kind");
     flip_swap_systems(ctx);
+    return 0;
+}
+
+// Two systems in progress side by side under the caller's control (the slab driver interleaves the two solves of a
+// substep: the collectives of one run under the kernels of the other).  Between flip_pair_begin and flip_pair_end the
+// context holds two system sets, each with a stream of its own; flip_pair_select makes one of them the active set, to
+// which every call then refers (flip_build_system, flip_pcg_dist_*, flip_get_stream, the projections).  Work enqueued
+// before begin is ordered before both streams; after end the context's own stream is ordered after both.
+extern "C" int flip_pair_begin(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(!ctx->pair_on, "flip_pair_begin: already begun");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    if (int rc = pair_streams(ctx)) return rc;
+    if (int rc = ensure_other_set(ctx)) return rc;
+    if (ctx->dist_sums) {   // a slab context: the second set needs the slab solve's arrays too
+        flip_swap_systems(ctx);
+        const int rc = slab_alloc_state(ctx);
+        flip_swap_systems(ctx);
+        if (rc) return rc;
+    }
+    hipStream_t main_stream = ctx->stream;
+    // the row count of flip_index_cells sits with the active set
+    if (int rc = flip_copy_i32(ctx, ctx->other.d_counts, ctx->d_counts, main_stream)) return rc;
+    FLIP_CHECK(hipEventRecord(ctx->pair_event[2], main_stream));
+    FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[0], ctx->pair_event[2], 0));
+    FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[1], ctx->pair_event[2], 0));
+    ctx->pair_main_stream = main_stream;
+    ctx->stream = ctx->pair_stream[0];
+    ctx->pair_slot = 0;
+    ctx->pair_on = true;
+    return 0;
+}
+extern "C" int flip_pair_select(flip_ctx *ctx, int slot) {
+    FLIP_REQUIRE(ctx && ctx->pair_on, "flip_pair_select: call flip_pair_begin first");
+    FLIP_REQUIRE(slot == 0 || slot == 1, "flip_pair_select: the slot is 0 or 1");
+    if (slot != ctx->pair_slot) {
+        flip_swap_systems(ctx);
+        ctx->pair_slot = slot;
+    }
+    ctx->stream = ctx->pair_stream[slot];
+    return 0;
+}
+extern "C" int flip_pair_end(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx && ctx->pair_on, "flip_pair_end: call flip_pair_begin first");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->pair_slot != 0) { flip_swap_systems(ctx); ctx->pair_slot = 0; }
+    ctx->stream = ctx->pair_main_stream;
+    ctx->pair_on = false;
+    for (int q = 0; q < 2; ++q) {
+        FLIP_CHECK(hipEventRecord(ctx->pair_event[q], ctx->pair_stream[q]));
+        FLIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->pair_event[q], 0));
+    }
     return 0;
 }
 

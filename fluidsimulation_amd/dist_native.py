@@ -16,11 +16,12 @@ from .binding import FlipError, PcgInfo, PRECOND_MULTIGRID, load_library
 
 DIST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libflip_dist.so")
 FORCE_SLAB = 1
+SEQUENTIAL_SOLVES = 2
 SUM, MAX = 0, 1
 
 # every symbol include/flip_dist.h declares
 DIST_EXPORTS = ["flip_dist_unique_id", "flip_dist_create", "flip_dist_create_with_transport", "flip_dist_destroy", "flip_dist_last_error",
-                "flip_dist_solve", "flip_dist_exchange_particles", "flip_dist_last_exchange", "flip_dist_all_reduce", "flip_dist_substep"]
+                "flip_dist_solve", "flip_dist_solve_pair", "flip_dist_exchange_particles", "flip_dist_last_exchange", "flip_dist_all_reduce", "flip_dist_substep"]
 
 ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -58,6 +59,7 @@ def load_dist_library(path: str = DIST_LIB_PATH):
         "flip_dist_destroy": (None, [vp]),
         "flip_dist_last_error": (C.c_char_p, [vp]),
         "flip_dist_solve": (C.c_int, [vp, C.c_int, C.c_float, C.c_double, i32, C.c_int, P(PcgInfo)]),
+        "flip_dist_solve_pair": (C.c_int, [vp, C.c_float, C.c_double, i32, C.c_int, P(PcgInfo), P(PcgInfo)]),
         "flip_dist_exchange_particles": (C.c_int, [vp, P(i64), P(i64)]),
         "flip_dist_last_exchange": (C.c_int, [vp, P(i64), P(i64)]),
         "flip_dist_all_reduce": (C.c_int, [vp, P(C.c_double), i32, C.c_int]),
@@ -125,7 +127,7 @@ class NativeDistributedSubstep:
     def __init__(self, ctx, layout, comm, device: int = 0, flip_pic_ratio: float = 0.95, tol: float = 1e-15, max_iter: int = 20000,
                  precond: int = PRECOND_MULTIGRID, density_projection: bool = True, overlap: int = 0, constrain: bool = False,
                  advect: bool = False, levelset_radius: float | None = None, rigid_body: bool = False, transport="rccl",
-                 force_slab: bool = False, particle_capacity: int | None = None):
+                 force_slab: bool = False, particle_capacity: int | None = None, sequential_solves: bool = False):
         self.lib = load_dist_library()
         self.ctx, self.layout, self.comm = ctx, layout, comm
         rank, world = comm.rank, comm.world
@@ -133,7 +135,8 @@ class NativeDistributedSubstep:
         starts = (C.c_int32 * (world + 1))(*layout.starts)
         cap = particle_capacity if particle_capacity is not None else ctx.particle_count() * 5 // 4 + 4096
         h = C.c_void_p()
-        flags = FORCE_SLAB if force_slab else 0
+        # sequential_solves: the two slab solves of a substep one after the other instead of side by side
+        flags = (FORCE_SLAB if force_slab else 0) | (SEQUENTIAL_SOLVES if sequential_solves else 0)
         self.transport = transport
         if transport == "rccl":
             uid = (C.c_uint8 * 128)()

@@ -181,7 +181,16 @@ void FluidSimulator::solve_pressure_divirgence(FluidDomain &domain, float dt) {
     _density_already_solved = false;
     if (_dist) {
         // over all slabs; flip_project_velocity leaves the body alone on a slab context, its update takes the J p of every slab
-        check_dist(flip_dist_solve(_dist, FLIP_SOLVE_DIVERGENCE, dt, solver_tolerance, solver_max_iterations, preconditioner, &info), "flip_dist_solve");
+        if (density_constraint && concurrent_solves) {
+            // both slab solves side by side: the collectives of one travel under the kernels of the other
+            flip_pcg_info info_density;
+            check_dist(flip_dist_solve_pair(_dist, dt, solver_tolerance, solver_max_iterations, preconditioner, &info, &info_density),
+                       "flip_dist_solve_pair");
+            last_density_solve = report(info_density);
+            _density_already_solved = true;
+        } else {
+            check_dist(flip_dist_solve(_dist, FLIP_SOLVE_DIVERGENCE, dt, solver_tolerance, solver_max_iterations, preconditioner, &info), "flip_dist_solve");
+        }
         last_divergence_solve = report(info);
         dev.check(flip_project_velocity(dev.ctx(), dt), "flip_project_velocity");
         if (!domain.solidObjs().empty()) {

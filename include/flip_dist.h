@@ -6,7 +6,8 @@
  * one to one: this library is that orchestration point for N contexts.  It calls libflip_hip.so only through
  * include/flip_hip.h.  What crosses ranks per substep:
  *   - per CG iteration two all-reduces of 16 doubles (p.Ap and the six rigid-body sums J p; r.r and r.z) and the plane
- *     exchanges of the slab preconditioner (flip_hip.h, "z-slab decomposition of the solve");
+ *     exchanges of the slab preconditioner (flip_hip.h, "z-slab decomposition of the solve"); the two solves of a substep
+ *     run side by side, each on a stream and a communicator of its own (flip_dist_solve_pair);
  *   - after the solve the ghost planes of the pressure;
  *   - after the particle update the particles near a slab face: one count message and one payload message per face
  *     (migration and the neighbours' ghost copies alike);
@@ -33,6 +34,7 @@ typedef struct flip_dist flip_dist;
 
 #define FLIP_DIST_UNIQUE_ID_BYTES 128
 #define FLIP_DIST_FORCE_SLAB 1 /* flags of flip_dist_create*: take the slab path also with world == 1 */
+#define FLIP_DIST_SEQUENTIAL_SOLVES 2 /* flip_dist_substep solves the two systems one after the other (default: side by side) */
 
 enum flip_dist_reduce_op { FLIP_DIST_SUM = 0, FLIP_DIST_MAX = 1 };
 
@@ -73,6 +75,14 @@ const char *flip_dist_last_error(const flip_dist *d);
  * needs the eliminated system, see flip_set_system_options); if one is, every rank returns the same error before any
  * collective of the solve. */
 int flip_dist_solve(flip_dist *d, int kind, float dt, double tol, int32_t max_iter, int precond, flip_pcg_info *info);
+
+/* Both solves of a substep (src/FluidSimulator.cpp:505 and :521) side by side: the two systems are assembled into two
+ * system sets of the context (flip_pair_begin), each with a stream and a communicator of its own, and the two slab
+ * solves advance in turn, so that the all-reduces and plane exchanges of one travel while the kernels of the other run.
+ * Each solve performs the operations flip_dist_solve performs, hence the same results.  On return the divergence
+ * system is the active one (flip_select_system switches, as after flip_solve_pair).  With one rank and no slab: flip_solve_pair. */
+int flip_dist_solve_pair(flip_dist *d, float dt, double tol, int32_t max_iter, int precond, flip_pcg_info *info_divergence,
+                         flip_pcg_info *info_density);
 
 /* Migration and ghost refresh after the particle update (no counterpart in the reference).  sent / received (may be
  * NULL): records toward / from the lower and the upper neighbour. */

@@ -296,6 +296,16 @@ int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int precond, fli
 int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_iter, int precond, flip_pcg_info *info_divergence,
                     flip_pcg_info *info_density);
 int flip_select_system(flip_ctx *ctx, int kind);
+/* Two systems in progress under the caller's control (no counterpart in the reference; the slab driver of
+ * include/flip_dist.h interleaves the two solves of a substep with these).  Between flip_pair_begin and flip_pair_end
+ * the context holds two system sets, each with a stream of its own; flip_pair_select(slot 0 | 1) makes one the active
+ * set, to which every call then refers: flip_build_system, flip_pcg_dist_*, flip_get_stream (the set's stream), the
+ * projections.  Work enqueued before begin is ordered before both streams; after end the context's own stream is ordered
+ * after both and slot 0 is the active set.  flip_pcg_solve and flip_solve_pair manage the sets themselves and are
+ * refused in between. */
+int flip_pair_begin(flip_ctx *ctx);
+int flip_pair_select(flip_ctx *ctx, int slot);
+int flip_pair_end(flip_ctx *ctx);
 /* y = A x for the assembled system on dense box vectors (parity hook for the SpMV kernel). */
 int flip_apply_operator(flip_ctx *ctx, const double *x_host, double *y_host);
 /* When enabled, flip_pcg_solve brackets a sample of its operator launches with HIP events and

@@ -348,7 +348,15 @@ def _gpu_rank_body(rank, out_dir, precond, kind, overlap, full=False, driver="py
             else:
                 step = DistributedSubstep(ctx, layout, Comm(), device=0, precond=precond, max_iter=20000, overlap=overlap, **_extras(sc, full))
             info = step.step(0.004)
-            p = ctx.download("pressure")
+            if driver == "native":
+                # the C driver solves the two systems side by side and leaves the divergence system active; the reference
+                # run below solves them one after the other on one set of arrays, which then holds the density solve's result
+                from fluidsimulation_amd import SOLVE_DENSITY, SOLVE_DIVERGENCE
+                ctx.select_system(SOLVE_DENSITY)
+                p = ctx.download("pressure")
+                ctx.select_system(SOLVE_DIVERGENCE)
+            else:
+                p = ctx.download("pressure")
             # after the exchange the set holds this rank's owned particles and fresh ghost copies
             pos, vel = ctx.download_particles()
             o0, o1 = layout.owned(rank)
@@ -556,7 +564,8 @@ def test_rigid_body_coupling_under_two_slabs_matches_the_single_context(driver):
 def test_native_driver_over_rccl_with_one_rank():
     """libflip_dist.so with its own RCCL communicator (ncclCommInitRank over one rank, ncclAllReduce after every CG kernel on
     the context's stream).  Forced onto the slab path it reproduces the Python-driven split-phase substep bit for bit (the
-    same kernels in the same order); left alone it falls through to the single-context substep, also bit for bit."""
+    same kernels in the same order), whether its two solves run side by side (two streams, two communicators) or one
+    after the other; left alone it falls through to the single-context substep, also bit for bit."""
     from fluidsimulation_amd import FlipContext, FlipSubstep, PRECOND_MULTIGRID
     from fluidsimulation_amd.distributed import Comm, DistributedSubstep, SlabLayout
     from fluidsimulation_amd.dist_native import NativeDistributedSubstep
@@ -564,12 +573,15 @@ def test_native_driver_over_rccl_with_one_rank():
     extras = _extras(sc, True)
     layout = SlabLayout(sc.dims[2], 1, 0)
 
-    def run(make):
+    def run(make, paired=False):
         with FlipContext(sc.desc()) as ctx:
             ctx.upload_scene(sc)
             step = make(ctx)
             infos = [step.step(0.004) for _ in range(2)]
             pos, vel = ctx.download_particles()
+            if paired:   # two system sets, the divergence one active: compare what the one-after-the-other runs leave, the density result
+                from fluidsimulation_amd import SOLVE_DENSITY
+                ctx.select_system(SOLVE_DENSITY)
             p = ctx.download("pressure")
             if hasattr(step, "close"):
                 step.close()
@@ -578,7 +590,9 @@ def test_native_driver_over_rccl_with_one_rank():
     ref_i, ref_pos, ref_vel, ref_p = run(lambda c: FlipSubstep(c, precond=PRECOND_MULTIGRID, max_iter=20000, concurrent_solves=True, **extras))
     py_i, py_pos, py_vel, py_p = run(lambda c: DistributedSubstep(c, layout, Comm(), device=0, precond=PRECOND_MULTIGRID, max_iter=20000, **extras))
     nat_i, nat_pos, nat_vel, nat_p = run(lambda c: NativeDistributedSubstep(c, layout, Comm(), device=0, precond=PRECOND_MULTIGRID,
-                                                                            max_iter=20000, force_slab=True, **extras))
+                                                                            max_iter=20000, force_slab=True, **extras), paired=True)
+    seq_i, seq_pos, seq_vel, seq_p = run(lambda c: NativeDistributedSubstep(c, layout, Comm(), device=0, precond=PRECOND_MULTIGRID,
+                                                                            max_iter=20000, force_slab=True, sequential_solves=True, **extras))
     thru_i, thru_pos, thru_vel, thru_p = run(lambda c: NativeDistributedSubstep(c, layout, Comm(), device=0, precond=PRECOND_MULTIGRID,
                                                                                 max_iter=20000, **extras))
     for i in nat_i + thru_i:
@@ -586,6 +600,10 @@ def test_native_driver_over_rccl_with_one_rank():
     # forced slab path over RCCL == the Python-driven split-phase loop
     assert np.array_equal(nat_pos, py_pos) and np.array_equal(nat_vel, py_vel) and np.array_equal(nat_p, py_p)
     assert [i["divergence"]["iterations"] for i in nat_i] == [i["divergence"]["iterations"] for i in py_i]
+    # the two slab solves side by side on two streams and two communicators (the default) == one after the other
+    assert np.array_equal(nat_pos, seq_pos) and np.array_equal(nat_vel, seq_vel) and np.array_equal(nat_p, seq_p)
+    assert [(i["divergence"]["iterations"], i["density"]["iterations"]) for i in nat_i] == \
+        [(i["divergence"]["iterations"], i["density"]["iterations"]) for i in seq_i]
     # fall-through == flip_solve_pair substep
     assert np.array_equal(thru_pos, ref_pos) and np.array_equal(thru_vel, ref_vel) and np.array_equal(thru_p, ref_p)
     # and the two paths agree to the solver tolerance
