@@ -1228,3 +1228,42 @@ def test_the_one_pass_particle_update_is_the_three_calls(advect, displace, body)
     (pa, va), (pb, vb) = results
     assert np.array_equal(pa, pb) and np.array_equal(va, vb)
     assert np.abs(va - sc.vel).max() > 0 and (not (advect or displace) or np.abs(pa - sc.pos).max() > 0)
+
+
+def test_pair_region_is_refused_where_it_cannot_work_and_leaves_the_context_as_it_was():
+    """flip_pair_begin / flip_pair_select / flip_pair_end hand the two system sets of a context to a caller that interleaves
+    two solves itself (the slab driver).  Calls that manage the sets on their own are refused in between, a select without
+    a begin is an error, and an empty region changes nothing: the substep after it equals the one of an untouched context."""
+    from fluidsimulation_amd import FlipError, FlipSubstep, PRECOND_MULTIGRID
+    sc = scenes.dam_break(32, ppc=4, seed=6)
+    rng = np.random.default_rng(4)
+    sc.vel = rng.normal(0, 0.3, sc.pos.shape)
+    results = []
+    for touched in (False, True):
+        with FlipContext(sc.desc()) as ctx:
+            ctx.upload_scene(sc)
+            step = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, concurrent_solves=True)
+            step.step(0.004)
+            if touched:
+                with pytest.raises(FlipError):
+                    ctx._check(ctx.lib.flip_pair_select(ctx.h, 1))
+                ctx._check(ctx.lib.flip_pair_begin(ctx.h))
+                with pytest.raises(FlipError):
+                    ctx._check(ctx.lib.flip_pair_begin(ctx.h))
+                with pytest.raises(FlipError):
+                    ctx.solve_pair(0.004, 1e-15, 0, PRECOND_MULTIGRID)
+                with pytest.raises(FlipError):
+                    ctx.pcg_solve(1e-15, 0, PRECOND_MULTIGRID)
+                with pytest.raises(FlipError):
+                    ctx._check(ctx.lib.flip_pair_select(ctx.h, 2))
+                ctx._check(ctx.lib.flip_pair_select(ctx.h, 1))
+                ctx._check(ctx.lib.flip_pair_select(ctx.h, 0))
+                ctx._check(ctx.lib.flip_pair_select(ctx.h, 1))
+                ctx._check(ctx.lib.flip_pair_end(ctx.h))
+                with pytest.raises(FlipError):
+                    ctx._check(ctx.lib.flip_pair_end(ctx.h))
+            info = step.step(0.004)
+            results.append((ctx.download_particles(), ctx.download("pressure"), [info[k]["iterations"] for k in ("divergence", "density")]))
+    (pa, va), qa, ia = results[0]
+    (pb, vb), qb, ib = results[1]
+    assert ia == ib and np.array_equal(pa, pb) and np.array_equal(va, vb) and np.array_equal(qa, qb)
