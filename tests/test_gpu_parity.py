@@ -1267,3 +1267,53 @@ def test_pair_region_is_refused_where_it_cannot_work_and_leaves_the_context_as_i
     (pa, va), qa, ia = results[0]
     (pb, vb), qb, ib = results[1]
     assert ia == ib and np.array_equal(pa, pb) and np.array_equal(va, vb) and np.array_equal(qa, qb)
+
+
+def test_config_dam_break_256_stages_against_the_oracle():
+    """BASELINE config 4's scene on one GPU, the bench configuration itself (side-drop dam break at 256^3, 12.4 M particles,
+    1.56 M rows), stage by stage against the 16-thread oracle at full size, bit for bit: binning, the P2G + density gather,
+    cell labels and row numbers, face fractions, and both assembled systems (stencil, diagonal, right-hand side).  The
+    solves are left to the property test: the oracle's Jacobi CG needs ~1200 iterations of 2 ms each per system here."""
+    sc = scenes.dam_break_slab(256, ppc=8, seed=12345)
+    rng = np.random.default_rng(31)
+    sc.vel = rng.normal(0.0, 0.15, sc.pos.shape)
+    dt = 0.001
+    o = Oracle(sc.desc(), threads=16)
+    cell_id, cell_start, perm, _ = o.bin_particles(sc.pos)
+    band2 = o.particle_mask(cell_start, 2)
+    want_uvw = o.p2g(sc.pos, sc.vel, cell_start, perm, band2)
+    want_density, _ = o.density(sc.pos, sc.mass, cell_start, perm, band2, sc.phi_fluid)
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        assert ctx.bin_particles() == 0
+        got_id, got_start, got_perm = ctx.download_binning()
+        assert np.array_equal(got_id, cell_id) and np.array_equal(got_start, cell_start) and np.array_equal(got_perm, perm)
+        del got_id, got_perm, cell_id
+        ctx.p2g()
+        for name, w in zip(("vel_u", "vel_v", "vel_w"), want_uvw):
+            assert np.array_equal(ctx.download(name), w), name
+        assert np.array_equal(ctx.download("density"), want_density)
+        del want_uvw
+        ctx.mark_valid_from_active(); ctx.extrapolate(2); ctx.update_prev(); ctx.add_forces(dt)
+        n_rows = ctx.index_cells(); ctx.face_fractions(); ctx.density()
+        uvw = [ctx.download(nm) for nm in ("vel_u", "vel_v", "vel_w")]
+        z32 = lambda: np.zeros(o.shape, np.float32)  # noqa: E731
+        label, index, want_rows = o.index_cells(o.particle_mask(cell_start, 1), sc.phi_fluid, sc.phi_solid, [z32(), z32(), z32()])
+        assert n_rows == want_rows and n_rows > 1500000
+        assert np.array_equal(ctx.download("label"), label) and np.array_equal(ctx.download("row_index"), index)
+        wm = o.weight_mask(sc.phi_fluid, sc.phi_fluid_bg)
+        fw = o.face_fractions(sc.phi_fluid, sc.phi_fluid_bg, wm)
+        w = o.face_fractions(sc.phi_solid, sc.phi_solid_bg, wm)
+        for name, want in zip(("weight_u", "weight_v", "weight_w"), w):
+            assert np.array_equal(ctx.download(name), want), name
+        for name, want in zip(("fluid_weight_u", "fluid_weight_v", "fluid_weight_w"), fw):
+            assert np.array_equal(ctx.download(name), want), name
+        off, diag, rhs = o.build_system(0, dt, label, sc.phi_fluid, sc.phi_solid, w, uvw=uvw)
+        ctx.build_system(SOLVE_DIVERGENCE, dt)
+        goff, gdiag, grhs = ctx.download_system()
+        assert np.array_equal(gdiag, diag) and np.array_equal(goff, off) and np.array_equal(grhs, rhs)
+        del off, goff
+        off2, diag2, rhs2 = o.build_system(1, dt, label, sc.phi_fluid, sc.phi_solid, w, density=want_density)
+        ctx.build_system(SOLVE_DENSITY, dt)
+        goff, gdiag, grhs = ctx.download_system()
+        assert np.array_equal(gdiag, diag2) and np.array_equal(goff, off2) and np.array_equal(grhs, rhs2)
