@@ -1317,3 +1317,33 @@ def test_config_dam_break_256_stages_against_the_oracle():
         ctx.build_system(SOLVE_DENSITY, dt)
         goff, gdiag, grhs = ctx.download_system()
         assert np.array_equal(gdiag, diag2) and np.array_equal(goff, off2) and np.array_equal(grhs, rhs2)
+
+
+def test_config_dam_break_256_first_substep_against_the_oracle():
+    """The whole hot-path substep of the bench configuration at full size against the 16-thread oracle, solves included
+    (the oracle runs the reference's Jacobi CG to the same 1e-15: about 1200 iterations per system; the device its
+    multigrid PCG, both solves side by side): pressure of the density solve on the labelled cells, projected velocity and
+    displacement grids, and the particles' new positions and velocities, at the bars of the small-size tests."""
+    from fluidsimulation_amd import FlipSubstep, PRECOND_MULTIGRID
+    sc = scenes.dam_break_slab(256, ppc=8, seed=12345)
+    rng = np.random.default_rng(31)
+    sc.vel = rng.normal(0.0, 0.15, sc.pos.shape)
+    dt = 0.001
+    o = Oracle(sc.desc(), threads=16)
+    ref = o.substep(fresh_state(sc, o), dt)
+    assert ref["n_rows"] > 1500000
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        info = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, max_iter=20000, concurrent_solves=True).step(dt)
+        for k in ("divergence", "density"):
+            assert info[k]["converged"] == 1 and info[k]["rel_residual_2"] < RES_TOL and info[k]["rows"] == ref["n_rows"], info[k]
+        lab = ref["label"].astype(bool)
+        assert rel_linf(ctx.download("pressure")[lab], ref["p_div"]) < 1e-8
+        ctx.select_system(SOLVE_DENSITY)
+        assert rel_linf(ctx.download("pressure")[lab], ref["p_den"]) < 1e-8
+        ctx.select_system(SOLVE_DIVERGENCE)
+        for name, want in zip(("disp_x", "disp_y", "disp_z"), ref["disp"]):
+            assert np.abs(ctx.download(name) - want).max() < POS_ATOL, name
+        pos, vel = ctx.download_particles()
+    assert np.abs(pos - ref["new_pos"]).max() < POS_ATOL
+    assert rel_linf(vel, ref["new_vel"]) < VEL_RTOL
