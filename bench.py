@@ -100,7 +100,6 @@ def parse():
     ap.add_argument("--warm-start", action="store_true",
                     help="flip_set_warm_start 1: a solve starts from the previous substep's solution instead of zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=8, help="CG iterations per timed repetition on the CPU (5 repetitions, median)")
     return ap.parse_args()
 
 
@@ -175,42 +174,40 @@ def cpu_stage_seconds(o, sc, args):
     return t, systems, sc.phi_fluid[label == 1] >= 0
 
 
-def cpu_baseline(sc, args, jacobi_iters):
-    """The CPU oracle (OpenMP port of the same stages, Jacobi CG as the reference runs it) timed on this host's cores,
-    once with 8 threads (what the reference pins Eigen to, src/FluidSimulator.cpp:658) and once with the cores available
-    (16 at most): every non-solver stage once at full size, CG iterations as the median of 5 repetitions of
-    `cpu_iters` iterations per solve, extrapolated to the iteration counts Jacobi CG needs on this scene (counted on the
-    GPU).  A baseline, not a target."""
+def cpu_baseline(sc, args):
+    """The CPU oracle (OpenMP port of the same stages, Jacobi CG as the reference runs it) timed on this host's cores, once
+    with 8 threads (what the reference pins Eigen to, src/FluidSimulator.cpp:658) and once with the cores available (16 at
+    most): one whole hot-path substep MEASURED each time -- every non-solver stage once at full size and both Jacobi-CG
+    solves run to the reference's tolerance.  About 10-20 s of CPU work.  A baseline, not a target."""
     from oracle import Oracle
     avail = min(os.cpu_count() or 1, 16)
     out = {}
     reference_solver = None
+    iters = None
     for threads in sorted({min(8, avail), avail}):
         o = Oracle(sc.desc(), threads=threads)
         t, systems, dependent = cpu_stage_seconds(o, sc, args)
-        t_iter = []
+        t_solve, iters = [], []
         for kind, (rowptr, col, val, b) in enumerate(systems):
             if kind == 0 and reference_solver is None:
                 reference_solver = reference_pcgsolver(rowptr, col, val, b, dependent)
             o.cg_jacobi(rowptr, col, val, b, tol=args.tol, max_iter=2)   # thread-pool and page warm-up, not timed
-            reps = []
-            for _ in range(5):
-                t0 = time.perf_counter()
-                _, it, _ = o.cg_jacobi(rowptr, col, val, b, tol=args.tol, max_iter=args.cpu_iters)
-                reps.append((time.perf_counter() - t0) / max(it, 1))
-            t_iter.append(float(np.median(reps)))
+            t0 = time.perf_counter()
+            _, it, _ = o.cg_jacobi(rowptr, col, val, b, tol=args.tol, max_iter=args.max_iter)
+            t_solve.append(time.perf_counter() - t0)
+            iters.append(int(it))
         fixed = sum(t.values())
-        total = fixed + t_iter[0] * jacobi_iters[0] + t_iter[1] * jacobi_iters[1]
-        out[threads] = {"value": 1.0 / total, "fixed_seconds": fixed, "ms_per_cg_iteration": [1e3 * v for v in t_iter],
+        total = fixed + t_solve[0] + t_solve[1]
+        out[threads] = {"value": 1.0 / total, "fixed_seconds": fixed, "solve_seconds": t_solve,
+                        "ms_per_cg_iteration": [1e3 * a / max(b, 1) for a, b in zip(t_solve, iters)],
                         "stage_seconds": {k: round(v, 4) for k, v in t.items()}}
     top = out[avail]
     return {"value": top["value"], "unit": "substeps/s", "cores": avail, "kind": "port",
             "value_8_threads": out[min(8, avail)]["value"], "reference_solver": reference_solver,
-            "sample": f"hot-path stages (no level-set rebuild, constrain, advection) once at full size ({top['fixed_seconds']:.2f} s) + "
-                      f"median of 5 x {args.cpu_iters} Jacobi-CG iterations per solve "
-                      f"({top['ms_per_cg_iteration'][0]:.1f}/{top['ms_per_cg_iteration'][1]:.1f} ms per iteration), extrapolated to the "
-                      f"{jacobi_iters[0]}+{jacobi_iters[1]} iterations Jacobi CG needs on this scene (counted on the GPU); particle "
-                      f"state as after the timed steps",
+            "cg_iterations": iters,
+            "sample": f"one whole hot-path substep (no level-set rebuild, constrain, advection) at full size, measured: the stages "
+                      f"({top['fixed_seconds']:.2f} s) and both Jacobi-CG solves to tol {args.tol:g} ({iters[0]} + {iters[1]} iterations, "
+                      f"{top['solve_seconds'][0]:.2f} + {top['solve_seconds'][1]:.2f} s); particle state as after the timed steps",
             "by_threads": {str(k): v for k, v in out.items()}}
 
 
@@ -468,7 +465,6 @@ def main():
         t_bin += e0.elapsed_time(e1) * 1e-3 / 3
     n_local = ctx.particle_count()
     entries, stages = [], {}
-    jacobi_iters = None
     if rank == 0:
         traffic, traffic_files = stored_traffic(args) if world == 1 else ({}, None)
         its_per_step = iters / args.steps
@@ -516,11 +512,6 @@ def main():
                                           note="flip_update_particles: G2P, RK3 advection with push-out and the density displacements in one pass "
                                                "(k_update_particles<true, true>); the three separate kernels took 0.34 + 0.44 + 0.18 ms"))
         ctx.upload_particles(*saved)
-        if world == 1 and not args.no_cpu_baseline and not slabs:
-            # iteration counts of the reference's own solver (Jacobi CG) on this scene, for the CPU extrapolation
-            probe = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=PRECOND_JACOBI).step(args.dt)
-            jacobi_iters = (probe["divergence"]["iterations"], probe["density"]["iterations"])
-
     if rank == 0:
         parallelism = "single GPU"
         if world > 1:
@@ -575,12 +566,12 @@ def main():
             "roofline_other_kernels": {e["kernel"]: e for e in entries if not e["dominant"]},
             "stages": stages,
         }
-        if jacobi_iters is not None:
+        if world == 1 and not args.no_cpu_baseline and not slabs:
             # the CPU works on the state the device has reached, not on the fluid at rest: from rest the vectors of the
             # first solve are full of denormals, which the reference's build (no flush-to-zero) crawls through
             sc.pos, sc.vel = ctx.download_particles()
             sc.phi_fluid = ctx.download("phi_fluid")
-            out["cpu_baseline"] = cpu_baseline(sc, args, jacobi_iters)
+            out["cpu_baseline"] = cpu_baseline(sc, args)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
