@@ -481,9 +481,10 @@ def main():
                     entries.append(roofline_entry(name, kt[name] * 1e-6, its_per_step, rows * BYTES[name], traffic,
                                                   note="one profiled iteration, device otherwise idle"))
             if kt.get("coarse_levels"):
-                # 13 launches, not one kernel: a stage.  ~34 B per level-0 row is what the levels below 0 move (1/8 + 1/64 + ...)
+                # 13 launches, not one kernel: a stage.  ~24 B per level-0 row is what the levels below 0 move: 169 B per row of a level
+                # that reads float operator copies (the first two), 249 B below, over 1/8 + 1/64 + ... of the rows
                 t_c = kt["coarse_levels"] * 1e-6
-                stages["coarse_levels"] = stage_entry(t_c, its_per_step, rows * 34, "all launches of the V-cycle below level 0 of one "
+                stages["coarse_levels"] = stage_entry(t_c, its_per_step, rows * 24, "all launches of the V-cycle below level 0 of one "
                                                       "iteration, run alone (bound by launch and dependent-load latency; beside the other "
                                                       "solve's level-0 kernels they mostly hide)")
         stages["binning"] = stage_entry(t_bin, 1, SORT_BYTES_PER_PARTICLE * n_local, "whole stage after a real substep: cell ids, scan, slots, "

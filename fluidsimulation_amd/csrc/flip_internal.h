@@ -72,6 +72,9 @@ struct flip_mg_level {
     double *cx = nullptr, *cy = nullptr, *cz = nullptr, *diag = nullptr, *inv = nullptr;
     double *x = nullptr, *b = nullptr, *t = nullptr;
     int32_t *rows = nullptr, *scan = nullptr, *n_rows = nullptr;
+    // float copies of the five operator arrays, for a level large enough to be bound by its bytes (the list-driven
+    // kernels read these; the next level is still coarsened from the doubles); nullptr on the small levels
+    float *cx_f = nullptr, *cy_f = nullptr, *cz_f = nullptr, *diag_f = nullptr, *inv_f = nullptr;
 };
 
 // The second assembled system of a context (flip_solve_pair keeps the divergence and the density system side by

@@ -124,12 +124,16 @@ __device__ __forceinline__ void d_mg_pre(const MgDev<CT> &L, double *__restrict_
         out[c] = t0 + L.a2 * t0 + L.c2 * ic * (bc - At);
     }
 }
-template <class CT>
+// TOP in the list-driven kernels: the level is level 0 of a solve (it has the regular-row flags, the alternating
+// residual buffers and the solver's scalars); the coarse levels that read float operator copies are the same code
+// under another name, which also keeps the two apart in a profile.
+template <class CT, bool TOP>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_pre(MgDev<CT> L, const int32_t *done, double *__restrict__ out) {
     // the stop flag and the row count are independent loads: both are in flight before either is looked at
     const int stop = done ? *done : 0;
     const long long n = *L.n_rows;
     if (stop) return;
+    if (!TOP) { L.reg = nullptr; L.S = nullptr; }   // known at compile time below level 0: the branches on them fold away
     d_mg_pre(L, out, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK, n);
 }
 
@@ -147,7 +151,7 @@ __device__ __forceinline__ double d_mg_second_step(const MgDev<CT> &L, const MgD
     const double x1 = in[c];
     return x1 + L.a2 * (x1 - v0) + L.c2 * (double)L.inv[c] * (b - d_mg_apply(L, c, in));
 }
-template <class CT, bool RZ>
+template <class CT, bool RZ, bool TOP>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, MgDev<double> C, const int32_t *done,
                                                          const double *__restrict__ in, double *out, double *__restrict__ partial) {
     __shared__ double scratch[4];
@@ -155,6 +159,7 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_smooth(MgDev<CT> L, MgDev<dou
     const int stop = done ? *done : 0;
     const long long n = *L.n_rows;
     if (stop) return;
+    if (!TOP) { L.reg = nullptr; L.S = nullptr; }
     const double *__restrict__ rhs = d_mg_rhs(L);
     double acc = 0.0;
     if (RZ) {
@@ -220,12 +225,13 @@ __device__ __forceinline__ void d_mg_post(const MgDev<CT> &F, const MgDev<double
         out[c] = v0 + F.c1 * (double)F.inv[c] * (rhs[c] - Av);
     }
 }
-template <class CT>
+template <class CT, bool TOP>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_post(MgDev<CT> F, MgDev<double> C, const int32_t *done,
                                                        const double *__restrict__ in, double *__restrict__ out) {
     const int stop = done ? *done : 0;
     const long long n = *F.n_rows;
     if (stop) return;
+    if (!TOP) { F.reg = nullptr; F.S = nullptr; }
     d_mg_post(F, C, in, out, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK, n);
 }
 
@@ -260,12 +266,13 @@ __device__ __forceinline__ void d_mg_restrict(const MgDev<CT> &F, const MgDev<do
         if (q < n && child == 0) C.b[cc] = s;
     }
 }
-template <class CT>
+template <class CT, bool TOP>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict(MgDev<CT> F, MgDev<double> C, const int32_t *done,
                                                            const double *__restrict__ v) {
     const int stop = done ? *done : 0;
     const long long n = *C.n_rows;
     if (stop) return;
+    if (!TOP) { F.reg = nullptr; F.S = nullptr; }
     d_mg_restrict(F, C, v, (long long)blockIdx.x * FLIP_BLOCK + threadIdx.x, (long long)gridDim.x * FLIP_BLOCK, n);
 }
 
@@ -494,6 +501,15 @@ __global__ void k_mg_narrow(long long B, const double *__restrict__ diag, const 
     inv_f[c] = (float)inv[c];
 }
 
+__global__ void k_mg_narrow_level(long long B, const double *__restrict__ cx, const double *__restrict__ cy, const double *__restrict__ cz,
+                                  const double *__restrict__ diag, const double *__restrict__ inv, float *__restrict__ cx_f,
+                                  float *__restrict__ cy_f, float *__restrict__ cz_f, float *__restrict__ diag_f, float *__restrict__ inv_f) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    cx_f[c] = (float)cx[c]; cy_f[c] = (float)cy[c]; cz_f[c] = (float)cz[c];
+    diag_f[c] = (float)diag[c]; inv_f[c] = (float)inv[c];
+}
+
 // ---------------------------------------------------------------------------------------------
 
 static hipError_t mg_alloc_padded(double **p, int64_t n, int64_t pad) {
@@ -510,11 +526,20 @@ void flip_mg_free(flip_ctx *ctx) {
         double **dp[] = { &L.cx, &L.cy, &L.cz, &L.diag, &L.inv, &L.x, &L.b, &L.t };
         for (double **q : dp)
             if (*q) { (void)hipFree(*q - L.pad); *q = nullptr; }
+        float **fp[] = { &L.cx_f, &L.cy_f, &L.cz_f, &L.diag_f, &L.inv_f };
+        for (float **q : fp)
+            if (*q) { (void)hipFree(*q - L.pad); *q = nullptr; }
         if (L.rows) (void)hipFree(L.rows);
         if (L.scan) (void)hipFree(L.scan);
         if (L.n_rows) (void)hipFree(L.n_rows);
     }
     ctx->mg.clear();
+}
+
+// levels of at most this many cells use the one-thread-per-cell kernels (FLIP_MG_DENSE_CELLS: tuning aid, 0 = never)
+static int64_t mg_dense_cells() {
+    static const int64_t v = [] { const char *e = getenv("FLIP_MG_DENSE_CELLS"); return e ? (int64_t)atoll(e) : (int64_t)131072; }();
+    return v;
 }
 
 static int mg_coarsest_pad(int nx, int ny) { return (int)(((int64_t)nx * ny + 1 + 15) / 16 * 16); }
@@ -540,6 +565,15 @@ static int mg_ensure_levels(flip_ctx *ctx) {
         double **dp[] = { &L.cx, &L.cy, &L.cz, &L.diag, &L.inv, &L.x, &L.b, &L.t };
         for (double **q : dp)
             if (e == hipSuccess) e = mg_alloc_padded(q, L.B, L.pad);
+        if (L.B > mg_dense_cells() && !getenv("FLIP_MG_WIDE_LEVELS")) {
+            float **fp[] = { &L.cx_f, &L.cy_f, &L.cz_f, &L.diag_f, &L.inv_f };
+            for (float **q : fp)
+                if (e == hipSuccess) {
+                    e = hipMalloc((void **)q, (size_t)(L.B + 2 * L.pad) * sizeof(float));
+                    if (e == hipSuccess) e = flip_zero_new(*q, (size_t)(L.B + 2 * L.pad) * sizeof(float));
+                    if (e == hipSuccess) *q += L.pad;
+                }
+        }
         if (e == hipSuccess) e = hipMalloc((void **)&L.rows, (size_t)L.B * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&L.scan, (size_t)(L.B + 1) * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&L.n_rows, 4);
@@ -584,6 +618,22 @@ static MgDev<double> mg_level(const flip_mg_level &S) {
     return L;
 }
 
+// The same level through the float copies of its operator (only where they exist).
+static MgDev<float> mg_level_narrow(const flip_mg_level &S) {
+    MgDev<float> L;
+    L.B = S.B; L.sy = S.nx; L.sz = (long long)S.nx * S.ny;
+    L.nx = S.nx; L.ny = S.ny; L.nz = S.nz;
+    L.cx = S.cx_f; L.cy = S.cy_f; L.cz = S.cz_f;
+    L.scale = 1.0;
+    { const MgCheb k = mg_cheb(); L.c1 = k.c1; L.a2 = k.a2; L.c2 = k.c2; }
+    L.diag = S.diag_f; L.inv = S.inv_f;
+    L.x = S.x; L.b = S.b; L.t = S.t;
+    L.b_alt = nullptr; L.S = nullptr;
+    L.reg = nullptr;
+    L.rows = S.rows; L.n_rows = S.n_rows;
+    return L;
+}
+
 template <class CT>
 static int mg_coarsen_into(flip_ctx *ctx, const MgDev<CT> &F, const double *fine_diag, flip_mg_level &S) {
     hipStream_t st = ctx->stream;
@@ -597,6 +647,10 @@ static int mg_coarsen_into(flip_ctx *ctx, const MgDev<CT> &F, const double *fine
     k_mg_compact<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.B, S.scan, S.rows);
     FLIP_LAUNCH_CHECK();
     if (int rc = flip_copy_i32(ctx, S.n_rows, S.scan + S.B, st)) return rc;
+    if (S.cx_f) {
+        k_mg_narrow_level<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.B, S.cx, S.cy, S.cz, S.diag, S.inv, S.cx_f, S.cy_f, S.cz_f, S.diag_f, S.inv_f);
+        FLIP_LAUNCH_CHECK();
+    }
     // vectors of a previous solve may be non-zero on cells that are no longer rows
     FLIP_CHECK(hipMemsetAsync(S.x, 0, (size_t)S.B * 8, st));
     FLIP_CHECK(hipMemsetAsync(S.t, 0, (size_t)S.B * 8, st));
@@ -634,12 +688,6 @@ static int mg_blocks(const flip_ctx *ctx, int64_t B) {
     return (int)(nb < 1 ? 1 : nb);
 }
 
-// levels of at most this many cells use the one-thread-per-cell kernels (FLIP_MG_DENSE_CELLS: tuning aid, 0 = never)
-static int64_t mg_dense_cells() {
-    static const int64_t v = [] { const char *e = getenv("FLIP_MG_DENSE_CELLS"); return e ? (int64_t)atoll(e) : (int64_t)131072; }();
-    return v;
-}
-
 // One V-cycle: z = M^-1 r on level 0, and the partials of r.z in slot 1 for the next direction kernel.
 int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed) {
     hipStream_t st = ctx->stream;
@@ -649,18 +697,24 @@ int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed) {
     MgDev<float> L0 = mg_level0(ctx);
     // ---- down: pre-smooth (result in x), restrict the residual ----
     const bool mark = ctx->kprof_arm;
-    if (!pre_smoothed) k_mg_pre<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.x);
+    if (!pre_smoothed) k_mg_pre<float, true><<<nblk, FLIP_BLOCK, 0, st>>>(L0, done, L0.x);
     if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[2], st));
-    k_mg_restrict<float><<<mg_blocks(ctx, ctx->mg[0].B * 8), FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x);
+    k_mg_restrict<float, true><<<mg_blocks(ctx, ctx->mg[0].B * 8), FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x);
     if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[3], st));
     const int64_t dense_max = mg_dense_cells();
     for (size_t l = 0; l + 1 < nl; ++l) {
         MgDev<double> F = mg_level(ctx->mg[l]);
         const int64_t B = ctx->mg[l].B, Bc = ctx->mg[l + 1].B;
+        if (ctx->mg[l].cx_f && Bc * 8 > dense_max) {
+            const MgDev<float> Fn = mg_level_narrow(ctx->mg[l]);
+            k_mg_pre<float, false><<<mg_blocks(ctx, B), FLIP_BLOCK, 0, st>>>(Fn, done, Fn.x);
+            k_mg_restrict<float, false><<<mg_blocks(ctx, Bc * 8), FLIP_BLOCK, 0, st>>>(Fn, mg_level(ctx->mg[l + 1]), done, Fn.x);
+            continue;
+        }
         if (B <= dense_max) k_mg_pre_dense<<<(unsigned)((B + FLIP_BLOCK - 1) / FLIP_BLOCK), FLIP_BLOCK, 0, st>>>(F, done, F.x);
-        else k_mg_pre<double><<<mg_blocks(ctx, B), FLIP_BLOCK, 0, st>>>(F, done, F.x);
+        else k_mg_pre<double, false><<<mg_blocks(ctx, B), FLIP_BLOCK, 0, st>>>(F, done, F.x);
         if (Bc * 8 <= dense_max) k_mg_restrict_dense<<<(unsigned)((Bc * 8 + FLIP_BLOCK - 1) / FLIP_BLOCK), FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x);
-        else k_mg_restrict<double><<<mg_blocks(ctx, Bc * 8), FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x);
+        else k_mg_restrict<double, false><<<mg_blocks(ctx, Bc * 8), FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x);
     }
     // ---- coarsest ----
     {
@@ -679,16 +733,22 @@ int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed) {
             k_mg_smooth_dense<<<nd, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.t, F.x);
             continue;
         }
-        k_mg_post<double><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x, F.t);
-        k_mg_smooth<double, false><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.t, F.x, nullptr);
+        if (ctx->mg[l].cx_f && ctx->mg[l + 1].B * 8 > dense_max) {
+            const MgDev<float> Fn = mg_level_narrow(ctx->mg[l]);
+            k_mg_post<float, false><<<nb, FLIP_BLOCK, 0, st>>>(Fn, mg_level(ctx->mg[l + 1]), done, Fn.x, Fn.t);
+            k_mg_smooth<float, false, false><<<nb, FLIP_BLOCK, 0, st>>>(Fn, mg_level(ctx->mg[l + 1]), done, Fn.t, Fn.x, nullptr);
+            continue;
+        }
+        k_mg_post<double, false><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.x, F.t);
+        k_mg_smooth<double, false, false><<<nb, FLIP_BLOCK, 0, st>>>(F, mg_level(ctx->mg[l + 1]), done, F.t, F.x, nullptr);
     }
     if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[4], st));
-    k_mg_post<float><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x, L0.t);
+    k_mg_post<float, true><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.x, L0.t);
     if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[5], st));
     if (ctx->slab_on && ctx->slab_overlap > 0) // r.z waits for the neighbours' share of z (flip_pcg_dist_combine)
-        k_mg_smooth<float, false><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.t, L0.x, nullptr);
+        k_mg_smooth<float, false, true><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.t, L0.x, nullptr);
     else
-        k_mg_smooth<float, true><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.t, L0.x, ctx->partial + 1 * FLIP_MAX_PCG_BLOCKS);
+        k_mg_smooth<float, true, true><<<nblk, FLIP_BLOCK, 0, st>>>(L0, mg_level(ctx->mg[0]), done, L0.t, L0.x, ctx->partial + 1 * FLIP_MAX_PCG_BLOCKS);
     if (mark) FLIP_CHECK(hipEventRecord(ctx->kprof[6], st));
     FLIP_LAUNCH_CHECK();
     return 0;

@@ -17,9 +17,9 @@ from bench import kernel_source_id  # noqa: E402
 GROUPS = {
     "k_pcg_direction": ["void k_pcg_direction<true>"],
     "k_pcg_update_pre": ["k_pcg_update_pre"],
-    "k_mg_restrict": ["void k_mg_restrict<float>"],
-    "k_mg_post": ["void k_mg_post<float>"],
-    "k_mg_smooth": ["void k_mg_smooth<float, true>"],
+    "k_mg_restrict": ["void k_mg_restrict<float, true>"],
+    "k_mg_post": ["void k_mg_post<float, true>"],
+    "k_mg_smooth": ["void k_mg_smooth<float, true, true>"],
     "k_gather": ["void k_gather<true, 2, 2, 2>", "void k_gather_clear<true>"],
     "k_g2p": ["k_g2p"],
     "k_update_particles": ["void k_update_particles<true, true>"],

@@ -4,7 +4,8 @@ alone, and nothing at all (measurement aid)."""
 import csv
 import sys
 
-FINE = ("k_pcg_direction", "k_pcg_update_pre", "k_mg_restrict<float", "k_mg_post<float", "k_mg_smooth<float", "k_mg_pre<float")
+FINE = ("k_pcg_direction", "k_pcg_update_pre", "k_mg_restrict<float, true>", "k_mg_post<float, true>", "k_mg_smooth<float, true, true>",
+        "k_mg_smooth<float, false, true>", "k_mg_pre<float, true>")
 rows = list(csv.DictReader(open(sys.argv[1])))
 iv = []
 for r in rows:
