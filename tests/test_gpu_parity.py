@@ -1347,3 +1347,70 @@ def test_config_dam_break_256_first_substep_against_the_oracle():
         pos, vel = ctx.download_particles()
     assert np.abs(pos - ref["new_pos"]).max() < POS_ATOL
     assert rel_linf(vel, ref["new_vel"]) < VEL_RTOL
+
+
+def test_config_cube_drop_128_first_substep_against_the_oracle():
+    """BASELINE config 2 at full size (cube drop at 128^3, 2.1 M particles): the whole hot-path substep against the
+    16-thread oracle, solves included (Jacobi CG to 1e-15 there, multigrid PCG with both solves side by side here), at the
+    bars of the small-size tests."""
+    from fluidsimulation_amd import FlipSubstep, PRECOND_MULTIGRID
+    sc = scenes.cube_drop(128, ppc=8, seed=12345, exact_levelset=False)
+    rng = np.random.default_rng(3)
+    sc.vel = rng.normal(0.0, 0.2, sc.pos.shape)
+    dt = 0.002
+    o = Oracle(sc.desc(), threads=16)
+    ref = o.substep(fresh_state(sc, o), dt)
+    assert ref["n_rows"] > 200000 and ref["err_div"] < RES_TOL and ref["err_den"] < RES_TOL
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        info = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, max_iter=20000, concurrent_solves=True).step(dt)
+        for k in ("divergence", "density"):
+            assert info[k]["converged"] == 1 and info[k]["rel_residual_2"] < RES_TOL and info[k]["rows"] == ref["n_rows"], info[k]
+        lab = ref["label"].astype(bool)
+        assert rel_linf(ctx.download("pressure")[lab], ref["p_div"]) < 1e-8
+        ctx.select_system(SOLVE_DENSITY)
+        assert rel_linf(ctx.download("pressure")[lab], ref["p_den"]) < 1e-8
+        ctx.select_system(SOLVE_DIVERGENCE)
+        for name, want in zip(("disp_x", "disp_y", "disp_z"), ref["disp"]):
+            assert np.abs(ctx.download(name) - want).max() < POS_ATOL, name
+        pos, vel = ctx.download_particles()
+    assert np.abs(pos - ref["new_pos"]).max() < POS_ATOL
+    assert rel_linf(vel, ref["new_vel"]) < VEL_RTOL
+
+
+def test_config_floating_ball_128_first_substep_against_the_oracle():
+    """BASELINE config 3 at full size (config 2 plus the half-density sphere, two-way coupled through J^T M^-1 J,
+    src/FluidSimulator.cpp:810-816): the whole hot-path substep against the 16-thread oracle, the rank-6 coupled
+    divergence solve and the density solve included -- pressures on the labelled cells, displacement grids, the particles
+    and the body's new velocity.  The particles inside the sphere are taken out first, as the reference's advection keeps
+    them outside solids (cells walled in by the body would otherwise form pockets whose pressure level is arbitrary)."""
+    from fluidsimulation_amd import FlipSubstep, PRECOND_MULTIGRID
+    sc = scenes.cube_drop(128, ppc=8, seed=12345, exact_levelset=False)
+    centre, radius_world = (0.5, 0.45, 0.5), 0.1
+    scenes.add_sphere(sc, radius_world=radius_world, centre_world=centre, density=500.0, vel=(0.05, -0.3, 0.02, 0.4, 0.0, -0.2))
+    dx = float(sc.dx)
+    keep = np.linalg.norm((sc.pos + 0.5) * dx - np.array(centre), axis=1) > radius_world + 0.5 * dx
+    assert 1000 < (~keep).sum() < keep.sum()
+    sc.pos, sc.vel, sc.mass = sc.pos[keep].copy(), sc.vel[keep].copy(), sc.mass[keep].copy()
+    sc.phi_fluid = scenes.fluid_levelset(sc, sc.pos)
+    rng = np.random.default_rng(2)
+    sc.vel = rng.normal(0.0, 0.1, sc.pos.shape)
+    dt = 0.002
+    o = Oracle(sc.desc(), threads=16)
+    st = fresh_state(sc, o)
+    st["obj"] = dict(phi=sc.phi_object, bg=sc.phi_object_bg, com=sc.object_com, minv=sc.object_minv, vel=sc.object_vel)
+    ref = o.substep(st, dt)
+    assert ref["n_rows"] > 200000 and ref["err_div"] < RES_TOL and ref["err_den"] < RES_TOL
+    with FlipContext(sc.desc()) as ctx:
+        ctx.upload_scene(sc)
+        info = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, max_iter=20000, rigid_body=True).step(dt)
+        for k in ("divergence", "density"):
+            assert info[k]["converged"] == 1 and info[k]["rel_residual_2"] < RES_TOL and info[k]["rows"] == ref["n_rows"], info[k]
+        lab = ref["label"].astype(bool)
+        assert rel_linf(ctx.download("pressure")[lab], ref["p_den"]) < 1e-8      # the density system was solved last
+        assert rel_linf(ctx.solid_object_velocity(), ref["obj_vel"]) < 1e-8
+        for name, want in zip(("disp_x", "disp_y", "disp_z"), ref["disp"]):
+            assert np.abs(ctx.download(name) - want).max() < POS_ATOL, name
+        pos, vel = ctx.download_particles()
+    assert np.abs(pos - ref["new_pos"]).max() < POS_ATOL
+    assert rel_linf(vel, ref["new_vel"]) < VEL_RTOL
