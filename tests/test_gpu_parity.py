@@ -997,25 +997,22 @@ def test_iteration_cap_is_honoured_whatever_the_previous_solve_took(concurrent):
             assert again[k]["converged"] == 1 and again[k]["rel_residual_2"] < RES_TOL, (k, again[k])
 
 
-def test_four_substeps_of_the_default_scene_follow_the_oracle():
-    """BASELINE config 1 (the cube drop at main.cpp's default 64^3) over FOUR whole substeps with the level set rebuilt
-    from the particles, both constrain_velocity calls and the RK3 advection switched on: the state a substep inherits
-    from the one before (valid flags, stale face weights, moved particles: src/FluidSimulator.cpp:343-345, 486-488) is
-    carried on the device and, independently, by the oracle; neither side is re-synchronised with the other.  After every
-    substep: labels and row count bit-exact, fluid level set equal to rounding, positions <= 1e-5 cell, velocities
-    <= 1e-4 relative."""
+def _whole_substeps_follow_the_oracle(sc, dt, n_steps):
+    """Whole substeps -- level set rebuilt from the particles (src/FluidSimulator.cpp:324), both constrain_velocity calls,
+    RK3 advection with push-out, density projection -- on the device and, independently, in the oracle: the state a
+    substep inherits from the one before (valid flags, stale face weights, moved particles: :343-345, :486-488) is carried
+    by each side on its own, neither is re-synchronised with the other.  After every substep: labels and row count
+    bit-exact, face fractions bit-exact, fluid level set equal to rounding, positions <= 1e-5 cell, velocities <= 1e-4
+    relative."""
     from fluidsimulation_amd import FlipSubstep, PRECOND_MULTIGRID
-    sc = scenes.cube_drop(64, ppc=4, seed=11, exact_levelset=False)
-    rng = np.random.default_rng(5)
-    sc.vel = rng.normal(0.0, 0.1, sc.pos.shape)
     radius = 1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0    # src/FluidSource.cpp:67
-    dt = 0.004
     o = Oracle(sc.desc(), threads=16)
     st = fresh_state(sc, o)
     with FlipContext(sc.desc()) as ctx:
         ctx.upload_scene(sc)
-        step = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, max_iter=20000, constrain=True, advect=True, levelset_radius=radius)
-        for k in range(4):
+        step = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, max_iter=20000, constrain=True, advect=True, levelset_radius=radius,
+                           concurrent_solves=True)
+        for k in range(n_steps):
             _, cell_start, perm, _ = o.bin_particles(st["pos"])
             st["phi_fluid"] = o.fluid_levelset(st["pos"], cell_start, perm, sc.phi_solid, radius)
             ref = o.substep(st, dt, max_iter=20000, constrain=True)
@@ -1033,6 +1030,25 @@ def test_four_substeps_of_the_default_scene_follow_the_oracle():
             assert np.abs(pos - new_pos).max() < POS_ATOL, k
             assert rel_linf(vel, ref["new_vel"]) < VEL_RTOL, k
             st = dict(st, pos=new_pos, vel=ref["new_vel"], w=ref["w"], valid=ref["valid"])
+    return ref["n_rows"]
+
+
+def test_four_substeps_of_the_default_scene_follow_the_oracle():
+    """BASELINE config 1 (the cube drop at main.cpp's default 64^3) over FOUR whole substeps with the level set rebuilt
+    from the particles, both constrain_velocity calls and the RK3 advection switched on."""
+    sc = scenes.cube_drop(64, ppc=4, seed=11, exact_levelset=False)
+    rng = np.random.default_rng(5)
+    sc.vel = rng.normal(0.0, 0.1, sc.pos.shape)
+    _whole_substeps_follow_the_oracle(sc, 0.004, 4)
+
+
+def test_two_whole_substeps_of_the_bench_configuration_follow_the_oracle():
+    """The configuration bench.py times, as it times it (side-drop dam break at 256^3, 12.4 M particles, dt = 0.001, the
+    whole loop body of advance_flip_pic except the source), over two consecutive substeps at full size."""
+    sc = scenes.dam_break_slab(256, ppc=8, seed=12345)
+    rng = np.random.default_rng(31)
+    sc.vel = rng.normal(0.0, 0.15, sc.pos.shape)
+    assert _whole_substeps_follow_the_oracle(sc, 0.001, 2) > 1500000
 
 
 def test_config_floating_ball_128_stages_against_the_oracle():
