@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -74,6 +75,21 @@ EXPORTS = [
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process can drive the device through one HIP/HSA runtime only.  PyTorch-ROCm wheels carry their own copy and load
+    it by path: imported after libflip_hip.so has pulled in the system's copy, torch brings a second runtime that finds no
+    device ("No HIP GPUs are available"), whereas a library loaded after torch resolves its libamdhip64 dependency to the
+    copy already in the process.  The distributed drivers of this package need torch (device tensors, torch.distributed),
+    so where torch is installed it is imported first, whatever the order the caller's own imports come in.
+    FLIP_NO_TORCH_PRELOAD=1 skips this for a process that will never import torch."""
+    if "torch" in sys.modules or os.environ.get("FLIP_NO_TORCH_PRELOAD") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def load_library(path: str = LIB_PATH):
     """Load libflip_hip.so.  Raises FlipError when it has not been built."""
     global _lib
@@ -82,6 +98,7 @@ def load_library(path: str = LIB_PATH):
     if not os.path.exists(path):
         raise FlipError(f"{path} not found: build it with `make -C fluidsimulation_amd/csrc` "
                         "(there is no CPU fallback for the HIP path)")
+    _one_hip_runtime()
     lib = C.CDLL(path)
     vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
     P = C.POINTER

@@ -213,11 +213,16 @@ extern "C" int flip_index_cells(flip_ctx *ctx, int32_t *n_rows) {
     if (int rc = flip_copy_i32(ctx, ctx->d_counts, ctx->row_index + B, st)) return rc;
     k_finish_index<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(B, ctx->label, ctx->row_index);
     FLIP_LAUNCH_CHECK();
-    int32_t n = 0;
-    FLIP_CHECK(hipMemcpyAsync(&n, ctx->d_counts, 4, hipMemcpyDeviceToHost, st));
-    FLIP_CHECK(hipStreamSynchronize(st));
-    ctx->n_rows = n;
-    if (n_rows) *n_rows = n;
+    // the count stays on the device unless the caller asks for it: reading it back makes the host wait for the stream and
+    // leaves the device idle until the next launch arrives (flip_pcg_solve fetches it if it needs Eigen's default limit)
+    ctx->n_rows = -1;
+    if (n_rows) {
+        int32_t n = 0;
+        FLIP_CHECK(hipMemcpyAsync(&n, ctx->d_counts, 4, hipMemcpyDeviceToHost, st));
+        FLIP_CHECK(hipStreamSynchronize(st));
+        ctx->n_rows = n;
+        *n_rows = n;
+    }
     return 0;
 }
 

@@ -971,7 +971,15 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
     FLIP_REQUIRE(ctx->pcg_blocks % 8 == 0 && ctx->pcg_blocks <= FLIP_MAX_PCG_BLOCKS, "bad PCG grid size");
     (void)who;
     hipStream_t st = ctx->stream;
-    if (max_iter <= 0) max_iter = 2 * (ctx->n_rows > 0 ? ctx->n_rows : 1);
+    if (max_iter <= 0) {   // Eigen's default: twice the number of rows
+        if (ctx->n_rows < 0) {   // flip_index_cells left the count on the device
+            int32_t n = 0;
+            FLIP_CHECK(hipMemcpyAsync(&n, ctx->d_counts, 4, hipMemcpyDeviceToHost, st));
+            FLIP_CHECK(hipStreamSynchronize(st));
+            ctx->n_rows = n;
+        }
+        max_iter = 2 * (ctx->n_rows > 0 ? ctx->n_rows : 1);
+    }
 
     // cells off the CG rows must read as zero in x and in the vectors the stencil reads at neighbours
     // Warm start: the last converged solution of a system of the same kind on these arrays is the guess (Eigen's

@@ -595,7 +595,11 @@ def test_native_driver_over_rccl_with_one_rank():
                                                                             max_iter=20000, force_slab=True, sequential_solves=True, **extras))
     thru_i, thru_pos, thru_vel, thru_p = run(lambda c: NativeDistributedSubstep(c, layout, Comm(), device=0, precond=PRECOND_MULTIGRID,
                                                                                 max_iter=20000, **extras))
-    for i in nat_i + thru_i:
+    # Eigen's default iteration limit (twice the row count) makes the solver fetch the count flip_index_cells left on the device
+    lim_i, lim_pos, lim_vel, lim_p = run(lambda c: NativeDistributedSubstep(c, layout, Comm(), device=0, precond=PRECOND_MULTIGRID,
+                                                                            max_iter=0, **extras))
+    assert np.array_equal(lim_pos, thru_pos) and np.array_equal(lim_vel, thru_vel) and np.array_equal(lim_p, thru_p)
+    for i in nat_i + thru_i + lim_i:
         assert i["divergence"]["converged"] == 1 and i["density"]["converged"] == 1
     # forced slab path over RCCL == the Python-driven split-phase loop
     assert np.array_equal(nat_pos, py_pos) and np.array_equal(nat_vel, py_vel) and np.array_equal(nat_p, py_p)
