@@ -65,7 +65,7 @@ EXPORTS = [
     "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_fluid_levelset_from_particles", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
     "flip_update_prev", "flip_update_diff", "flip_swap_velocity_buffers", "flip_swap_valid_masks", "flip_velocity_max", "flip_velocity_max_static", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_redistribute_overdense", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
-    "flip_update_particles", "flip_set_system_options", "flip_set_warm_start", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_pair_begin", "flip_pair_select", "flip_pair_end", "flip_project_velocity",
+    "flip_update_particles", "flip_set_system_options", "flip_set_warm_start", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_pair_begin", "flip_pair_select", "flip_pair_end", "flip_set_side_stream", "flip_side_fork", "flip_side_select", "flip_side_join", "flip_project_velocity",
     "flip_project_displacement", "flip_set_slab", "flip_solid_coupling_partial", "flip_solid_velocity_apply", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
     "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish", "flip_set_slab_overlap",
     "flip_pcg_dist_precondition", "flip_pcg_dist_combine", "flip_particles_reserve", "flip_particles_pack",
@@ -148,6 +148,10 @@ def load_library(path: str = LIB_PATH):
         "flip_pair_begin": (C.c_int, [vp]),
         "flip_pair_select": (C.c_int, [vp, C.c_int]),
         "flip_pair_end": (C.c_int, [vp]),
+        "flip_set_side_stream": (C.c_int, [vp, C.c_int]),
+        "flip_side_fork": (C.c_int, [vp]),
+        "flip_side_select": (C.c_int, [vp, C.c_int]),
+        "flip_side_join": (C.c_int, [vp]),
         "flip_update_particles": (C.c_int, [vp, f32, f32, C.c_int, C.c_int]),
         "flip_system_download": (C.c_int, [vp, vp, vp, vp]),
         "flip_pcg_solve": (C.c_int, [vp, f64, i32, C.c_int, P(PcgInfo)]),
@@ -337,9 +341,10 @@ class FlipContext:
         self._check(self.lib.flip_velocity_max_static(self.h, out))
         return np.array(out[:], dtype=np.float64)
 
-    def index_cells(self) -> int:
-        n = C.c_int32(0)
-        self._check(self.lib.flip_index_cells(self.h, C.byref(n)))
+    def index_cells(self, want_count: bool = True) -> int:
+        """Number of labelled cells; with want_count=False nothing is read back (no host wait) and -1 is returned."""
+        n = C.c_int32(-1)
+        self._check(self.lib.flip_index_cells(self.h, C.byref(n) if want_count else None))
         return n.value
 
     def face_fractions(self):
@@ -410,6 +415,19 @@ class FlipContext:
 
     def select_system(self, kind: int):
         self._check(self.lib.flip_select_system(self.h, kind))
+
+    # the context's second stream for stages of a substep that do not depend on each other (include/flip_hip.h)
+    def set_side_stream(self, on: bool):
+        self._check(self.lib.flip_set_side_stream(self.h, 1 if on else 0))
+
+    def side_fork(self):
+        self._check(self.lib.flip_side_fork(self.h))
+
+    def side_select(self, side: bool):
+        self._check(self.lib.flip_side_select(self.h, 1 if side else 0))
+
+    def side_join(self):
+        self._check(self.lib.flip_side_join(self.h))
 
     def set_profiling(self, on: bool):
         self._check(self.lib.flip_set_profiling(self.h, 1 if on else 0))

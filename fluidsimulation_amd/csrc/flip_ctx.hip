@@ -136,6 +136,13 @@ void flip_swap_systems(flip_ctx *c) {
 extern "C" void flip_ctx_destroy(flip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->side_selected) { c->stream = c->side_main_stream; c->side_selected = false; }
+    if (c->side_stream) {
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipStreamDestroy(c->side_stream);
+    }
+    for (hipEvent_t e : c->side_event)
+        if (e) (void)hipEventDestroy(e);
     (void)hipStreamSynchronize(c->stream);
     free_particles(c);
     flip_free_system(c);
@@ -154,7 +161,7 @@ extern "C" void flip_ctx_destroy(flip_ctx *c) {
     for (int b = 0; b < 4; ++b)
         for (int a = 0; a < 3; ++a) dfree(c->vel[b][a]);
     for (int a = 0; a < 3; ++a) {
-        dfree(c->disp[a]); dfree(c->wgt[a]); dfree(c->fwgt[a]); dfree(c->owgt[a]);
+        dfree(c->disp[a]); dfree(c->wgt[a]); dfree(c->fwgt[a]); dfree(c->owgt[a]); dfree(c->wgt_back[a]); dfree(c->owgt_back[a]);
         dfree(c->valid[0][a]); dfree(c->valid[1][a]);
     }
     for (int a = 0; a < 6; ++a) dfree(c->J[a]);
@@ -186,6 +193,7 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     c->device = device;
     c->gather_mode = flip_default_gather_mode();
     c->stream = (hipStream_t)stream;
+    if (const char *e = getenv("FLIP_SIDE_STREAM")) c->side_enabled = atoi(e) != 0;   // A/B measurements
     const int64_t B = c->B;
 
     hipError_t e = hipSuccess;
@@ -196,12 +204,12 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
     for (int b = 0; b < 4; ++b)
         for (int a = 0; a < 3; ++a) A(c->vel[b][a], B)
     for (int a = 0; a < 3; ++a) {
-        A(c->disp[a], B) A(c->wgt[a], B) A(c->fwgt[a], B) A(c->owgt[a], B)
+        A(c->disp[a], B) A(c->wgt[a], B) A(c->fwgt[a], B) A(c->owgt[a], B) A(c->wgt_back[a], B) A(c->owgt_back[a], B)
         A(c->valid[0][a], B) A(c->valid[1][a], B)
     }
     for (int a = 0; a < 6; ++a) A(c->J[a], B)
-    A(c->density, B) A(c->active, B) A(c->active_back, B) A(c->label, B) A(c->band, B) A(c->seed, B)
-    A(c->tmp_u8, B) A(c->row_index, B + 1)
+    A(c->density, B) A(c->active, B) A(c->active_back, B) A(c->label, B) A(c->band, B + 16) A(c->seed, B + 16)
+    A(c->tmp_u8, B + 16) A(c->row_index, B + 1)
     {
         const int64_t plane = (int64_t)desc->nx * desc->ny;
         c->pad = ((plane + FLIP_BLOCK + 63) / 64) * 64;
@@ -462,62 +470,199 @@ extern "C" int flip_particles_download_mass(flip_ctx *ctx, float *mass) {
 extern "C" int64_t flip_particles_count(const flip_ctx *ctx) { return ctx ? ctx->n : -1; }
 
 // ---------------------------------------------------------------------------------------------
-// Exclusive scan of int32, three kernels: per-block scan of 2048 items, scan of the block sums
-// (recursively), uniform add.  Deterministic (integers).
+// A second stream inside a substep.  Every entry point enqueues on ctx->stream; between flip_side_select(ctx, 1) and
+// flip_side_select(ctx, 0) that is the side stream.  The caller puts only stages there that neither read what the main
+// stream's stages write nor write what they read (include/flip_hip.h lists the two chains of a substep that qualify).
 
-#define SCAN_ITEMS 8
-#define SCAN_TILE (FLIP_BLOCK * SCAN_ITEMS)
+// A process has few hardware queues (four by default), the runtime deals its streams out to them, and two streams on
+// one queue run in that queue's order: a new stream may well share the queue of the context's own stream and overlap
+// nothing.  Which queue a stream got cannot be asked, so it is measured: a kernel that spins for a fixed time runs on
+// the context's stream and on a candidate; if the two take one kernel's time the candidate is kept, else the next is
+// tried.  The last candidate is kept whatever it measures (the side stream is then merely of no use).
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static int pick_side_stream(flip_ctx *ctx) {
+    int rate_khz = 100000;   // wall_clock64 ticks per millisecond
+    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, ctx->device);
+    const long long ticks = (long long)rate_khz / 5;   // 0.2 ms
+    hipEvent_t ev[3] = {};
+    for (hipEvent_t &e : ev) FLIP_CHECK(hipEventCreate(&e));
+    hipStream_t keep = nullptr;
+    std::vector<hipStream_t> rejected;
+    int rc = 0;
+    for (int attempt = 0; attempt < 6 && !keep && !rc; ++attempt) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { rc = flip_fail(ctx, "hipStreamCreateWithFlags of the side stream", __FILE__, __LINE__); break; }
+        bool ok = hipEventRecord(ev[0], ctx->stream) == hipSuccess && hipStreamWaitEvent(cand, ev[0], 0) == hipSuccess;
+        if (ok) {
+            k_spin<<<1, 64, 0, ctx->stream>>>(ticks);
+            k_spin<<<1, 64, 0, cand>>>(ticks);
+            ok = hipGetLastError() == hipSuccess && hipEventRecord(ev[1], ctx->stream) == hipSuccess && hipEventRecord(ev[2], cand) == hipSuccess
+                 && hipEventSynchronize(ev[1]) == hipSuccess && hipEventSynchronize(ev[2]) == hipSuccess;
+        }
+        float ms_main = 0.f, ms_cand = 0.f;
+        ok = ok && hipEventElapsedTime(&ms_main, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&ms_cand, ev[0], ev[2]) == hipSuccess;
+        if (!ok) { (void)hipStreamDestroy(cand); rc = flip_fail(ctx, "probing the side stream", __FILE__, __LINE__); break; }
+        const float both = ms_main > ms_cand ? ms_main : ms_cand;
+        if (both < 0.33f || attempt == 5) keep = cand;   // side by side: about 0.2 ms; one after the other: 0.4 ms
+        else rejected.push_back(cand);                   // kept alive until the choice is made, so that the next one lands elsewhere
+    }
+    for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    if (rc) return rc;
+    ctx->side_stream = keep;
+    return 0;
+}
 
-__global__ void k_scan_tile(int32_t *data, long long n, int32_t *block_sums) {
+extern "C" int flip_set_side_stream(flip_ctx *ctx, int enabled) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(!ctx->side_forked && !ctx->side_selected, "flip_set_side_stream: between flip_side_fork and flip_side_join");
+    ctx->side_enabled = enabled != 0;
+    return 0;
+}
+extern "C" int flip_side_fork(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx, "null context");
+    FLIP_REQUIRE(!ctx->side_selected, "flip_side_fork: the side stream is selected");
+    FLIP_REQUIRE(!ctx->pair_on, "flip_side_fork: inside flip_pair_begin .. flip_pair_end");
+    if (!ctx->side_enabled) return 0;
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->side_stream) {
+        if (int rc = pick_side_stream(ctx)) return rc;
+        for (hipEvent_t &e : ctx->side_event) FLIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (ctx->side_forked) { // a second fork before the join: the side work so far also precedes what follows on the side
+        return 0;
+    }
+    FLIP_CHECK(hipEventRecord(ctx->side_event[0], ctx->stream));
+    FLIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->side_event[0], 0));
+    ctx->side_forked = true;
+    return 0;
+}
+extern "C" int flip_side_select(flip_ctx *ctx, int side) {
+    FLIP_REQUIRE(ctx, "null context");
+    if (!ctx->side_enabled) return 0;
+    if (side) {
+        FLIP_REQUIRE(ctx->side_forked, "flip_side_select: call flip_side_fork first");
+        if (!ctx->side_selected) {
+            ctx->side_main_stream = ctx->stream;
+            ctx->stream = ctx->side_stream;
+            ctx->side_selected = true;
+        }
+    } else if (ctx->side_selected) {
+        ctx->stream = ctx->side_main_stream;
+        ctx->side_selected = false;
+    }
+    return 0;
+}
+extern "C" int flip_side_join(flip_ctx *ctx) {
+    FLIP_REQUIRE(ctx, "null context");
+    if (ctx->side_selected) {
+        ctx->stream = ctx->side_main_stream;
+        ctx->side_selected = false;
+    }
+    if (!ctx->side_forked) return 0;
+    ctx->side_forked = false;
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    FLIP_CHECK(hipEventRecord(ctx->side_event[1], ctx->side_stream));
+    FLIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->side_event[1], 0));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exclusive scan of int32 in place, reduce then scan: the sum of every tile of 4096 items (one read of the data), the
+// scan of those sums (one workgroup for up to 4096 tiles, the same three steps again above that), then every tile scans
+// itself starting from its offset (one read, one write).  A wave owns 1024 consecutive items of a tile and reads them in
+// four rounds of one int4 per lane, 1 KB per instruction.  Deterministic (integers).
+
+#define SCAN_ROUNDS 4
+#define SCAN_TILE (FLIP_BLOCK * 4 * SCAN_ROUNDS)
+
+__device__ __forceinline__ int4 d_scan_load(const int32_t *__restrict__ data, long long at, long long n, bool vec) {
+    if (vec && at + 4 <= n) return *reinterpret_cast<const int4 *>(data + at);
+    int4 v = make_int4(0, 0, 0, 0);
+    if (at < n) v.x = data[at];
+    if (at + 1 < n) v.y = data[at + 1];
+    if (at + 2 < n) v.z = data[at + 2];
+    if (at + 3 < n) v.w = data[at + 3];
+    return v;
+}
+__device__ __forceinline__ long long d_scan_at(int q) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return (long long)blockIdx.x * SCAN_TILE + (long long)wave * (SCAN_TILE / 4) + q * 256 + 4 * lane;
+}
+__global__ void k_scan_sums(const int32_t *__restrict__ data, long long n, int32_t *__restrict__ sums, int vec) {
     __shared__ int32_t wave_tot[4];
-    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-    int32_t v[SCAN_ITEMS];
     int32_t s = 0;
 #pragma unroll
-    for (int q = 0; q < SCAN_ITEMS; ++q) {
-        v[q] = (base + q < n) ? data[base + q] : 0;
-        s += v[q];
+    for (int q = 0; q < SCAN_ROUNDS; ++q) {
+        const int4 v = d_scan_load(data, d_scan_at(q), n, vec != 0);
+        s += v.x + v.y + v.z + v.w;
     }
-    // inclusive scan of s across the wave
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int32_t incl = s;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int32_t t = __shfl_up(incl, off, FLIP_WAVE);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, FLIP_WAVE);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = s;
     __syncthreads();
-    int32_t wave_off = 0;
-    for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
-    int32_t run = wave_off + incl - s;
-#pragma unroll
-    for (int q = 0; q < SCAN_ITEMS; ++q) {
-        if (base + q < n) data[base + q] = run;
-        run += v[q];
-    }
-    if (threadIdx.x == FLIP_BLOCK - 1 && block_sums) block_sums[blockIdx.x] = run;
+    if (threadIdx.x == 0) sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
 }
-__global__ void k_scan_add(int32_t *data, long long n, const int32_t *block_offsets) {
-    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-    const int32_t off = block_offsets[blockIdx.x];
+// offsets == nullptr: the data are one tile
+__global__ void k_scan_tile(int32_t *data, long long n, const int32_t *__restrict__ offsets, int vec) {
+    __shared__ int32_t wave_tot[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int4 v[SCAN_ROUNDS];
+    int32_t excl[SCAN_ROUNDS];
+    int32_t carry = 0;
 #pragma unroll
-    for (int q = 0; q < SCAN_ITEMS; ++q)
-        if (base + q < n) data[base + q] += off;
+    for (int q = 0; q < SCAN_ROUNDS; ++q) v[q] = d_scan_load(data, d_scan_at(q), n, vec != 0);
+#pragma unroll
+    for (int q = 0; q < SCAN_ROUNDS; ++q) {
+        const int32_t s = v[q].x + v[q].y + v[q].z + v[q].w;
+        int32_t incl = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t t = __shfl_up(incl, off, FLIP_WAVE);
+            if (lane >= off) incl += t;
+        }
+        excl[q] = carry + incl - s;
+        carry += __shfl(incl, 63, FLIP_WAVE);
+    }
+    if (lane == 0) wave_tot[wave] = carry;
+    __syncthreads();
+    int32_t base = offsets ? offsets[blockIdx.x] : 0;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+#pragma unroll
+    for (int q = 0; q < SCAN_ROUNDS; ++q) {
+        const long long at = d_scan_at(q);
+        int4 o;
+        o.x = base + excl[q];
+        o.y = o.x + v[q].x;
+        o.z = o.y + v[q].y;
+        o.w = o.z + v[q].z;
+        if (vec && at + 4 <= n) *reinterpret_cast<int4 *>(data + at) = o;
+        else {
+            if (at < n) data[at] = o.x;
+            if (at + 1 < n) data[at + 1] = o.y;
+            if (at + 2 < n) data[at + 2] = o.z;
+            if (at + 3 < n) data[at + 3] = o.w;
+        }
+    }
 }
 
 static int scan_rec(flip_ctx *ctx, int32_t *data, int64_t n, int32_t *tmp, int64_t tmp_len) {
     const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const int vec = ((uintptr_t)data & 15) == 0 ? 1 : 0;
     if (nb <= 1) {
-        k_scan_tile<<<1, FLIP_BLOCK, 0, ctx->stream>>>(data, n, nullptr);
+        k_scan_tile<<<1, FLIP_BLOCK, 0, ctx->stream>>>(data, n, nullptr, vec);
         FLIP_LAUNCH_CHECK();
         return 0;
     }
-    FLIP_REQUIRE(nb <= tmp_len, "scan scratch too small");
-    k_scan_tile<<<(int)nb, FLIP_BLOCK, 0, ctx->stream>>>(data, n, tmp);
+    const int64_t nb4 = (nb + 3) & ~(int64_t)3;   // the next level's sums start on a 16-byte boundary
+    FLIP_REQUIRE(nb4 <= tmp_len, "scan scratch too small");
+    k_scan_sums<<<(int)nb, FLIP_BLOCK, 0, ctx->stream>>>(data, n, tmp, vec);
     FLIP_LAUNCH_CHECK();
-    if (int rc = scan_rec(ctx, tmp, nb, tmp + nb, tmp_len - nb)) return rc;
-    k_scan_add<<<(int)nb, FLIP_BLOCK, 0, ctx->stream>>>(data, n, tmp);
+    if (int rc = scan_rec(ctx, tmp, nb, tmp + nb4, tmp_len - nb4)) return rc;
+    k_scan_tile<<<(int)nb, FLIP_BLOCK, 0, ctx->stream>>>(data, n, tmp, vec);
     FLIP_LAUNCH_CHECK();
     return 0;
 }
@@ -530,9 +675,9 @@ int flip_copy_i32(flip_ctx *ctx, int32_t *dst, const int32_t *src, hipStream_t s
 }
 
 int flip_exclusive_scan(flip_ctx *ctx, int32_t *data, int64_t n) {
-    // scratch for all recursion levels: nb + nb/2048 + ... < nb + nb/1024 + 4
-    const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    const int64_t need = nb + nb / 1024 + 8;
+    // scratch for the sums of every level
+    int64_t need = 8;
+    for (int64_t m = (n + SCAN_TILE - 1) / SCAN_TILE; m > 1; m = (m + SCAN_TILE - 1) / SCAN_TILE) need += (m + 3) & ~(int64_t)3;
     if (need > ctx->scan_tmp_len) {
         dfree(ctx->scan_tmp);
         hipError_t e = dalloc(&ctx->scan_tmp, need);

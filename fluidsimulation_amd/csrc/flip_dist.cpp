@@ -75,9 +75,13 @@ int fail(flip_dist *d, const std::string &what) {
 int fail_ctx(flip_dist *d, const char *call) {
     return fail(d, std::string(call) + ": " + flip_last_error(d->ctx));
 }
-#define DIST_FLIP(call)                                   \
-    do {                                                  \
-        if ((call) != 0) return fail_ctx(d, #call);       \
+static const bool g_dist_trace = getenv("FLIP_DIST_TRACE") != nullptr;   // every library call named on stderr before it is made
+static const bool g_dist_trace_sync = g_dist_trace && atoi(getenv("FLIP_DIST_TRACE")) > 1;   // ... and waited for
+#define DIST_FLIP(call)                                                         \
+    do {                                                                        \
+        if (g_dist_trace) { fprintf(stderr, "flip_dist: %s\n", #call); fflush(stderr); } \
+        if ((call) != 0) return fail_ctx(d, #call);                             \
+        if (g_dist_trace_sync) (void)hipDeviceSynchronize();                    \
     } while (0)
 #define DIST_HIP(call)                                                                                   \
     do {                                                                                                 \
@@ -437,8 +441,15 @@ extern "C" int flip_dist_substep(flip_dist *d, float dt, const flip_dist_step_op
     flip_ctx *c = d->ctx;
     memset(info, 0, 2 * sizeof(flip_pcg_info));
     const bool body = o->rigid_body != 0;
+    // Stages that do not depend on each other go to the context's two streams (flip_side_fork / select / join); a failed
+    // call leaves through the guard, which puts the context back on its own stream.
+    struct SideGuard { flip_ctx *c; ~SideGuard() { (void)flip_side_join(c); } } side_guard{ c };
     DIST_FLIP(flip_bin_particles(c, nullptr));
     if (o->levelset_radius > 0.f) DIST_FLIP(flip_fluid_levelset_from_particles(c, o->levelset_radius, 3.0f)); // :324
+    DIST_FLIP(flip_side_fork(c));
+    DIST_FLIP(flip_side_select(c, 1));
+    DIST_FLIP(flip_index_cells(c, nullptr));                  // :486  (reads the face fractions of the previous substep)
+    DIST_FLIP(flip_side_select(c, 0));
     DIST_FLIP(flip_p2g(c));                                   // :337
     DIST_FLIP(flip_mark_valid_from_active(c));                // :343-345
     DIST_FLIP(flip_extrapolate(c, 2));                        // :349
@@ -446,14 +457,22 @@ extern "C" int flip_dist_substep(flip_dist *d, float dt, const flip_dist_step_op
         DIST_FLIP(flip_constrain_velocity(c, 0));             // :357
         if (body) DIST_FLIP(flip_constrain_velocity(c, 1));   // :358-361
     }
+    DIST_FLIP(flip_side_select(c, 1));
+    DIST_FLIP(flip_face_fractions(c));                        // :488  (writes the other buffer: the calls above keep the old values)
+    DIST_FLIP(flip_side_select(c, 0));
     DIST_FLIP(flip_update_prev(c));                           // :367
     DIST_FLIP(flip_add_forces(c, dt));                        // :373
-    DIST_FLIP(flip_index_cells(c, nullptr));                  // :486
-    DIST_FLIP(flip_face_fractions(c));                        // :488
     DIST_FLIP(flip_density(c, nullptr));                      // :491
+    DIST_FLIP(flip_side_join(c));
     if (o->density_projection && (!d->slab || d->pair_solves)) {
         // both solves side by side (:505 and :521): on one context flip_solve_pair, over slabs the two slab solves in turn
         if (flip_dist_solve_pair(d, dt, o->tol, o->max_iter, o->precond, &info[0], &info[1])) return 1;
+        DIST_FLIP(flip_side_fork(c));
+        DIST_FLIP(flip_side_select(c, 1));
+        DIST_FLIP(flip_select_system(c, FLIP_SOLVE_DENSITY));
+        DIST_FLIP(flip_project_displacement(c, dt));          // :523
+        DIST_FLIP(flip_select_system(c, FLIP_SOLVE_DIVERGENCE));
+        DIST_FLIP(flip_side_select(c, 0));
         DIST_FLIP(flip_project_velocity(c, dt));              // :507
         if (body && d->slab) {
             // V += dt Minv (J p), J p summed over every slab's rows (:1095-1100)
@@ -462,9 +481,6 @@ extern "C" int flip_dist_substep(flip_dist *d, float dt, const flip_dist_step_op
             if (flip_dist_all_reduce(d, jp, 6, FLIP_DIST_SUM)) return 1;
             DIST_FLIP(flip_solid_velocity_apply(c, dt, jp));
         }
-        DIST_FLIP(flip_select_system(c, FLIP_SOLVE_DENSITY));
-        DIST_FLIP(flip_project_displacement(c, dt));          // :523
-        DIST_FLIP(flip_select_system(c, FLIP_SOLVE_DIVERGENCE));
     } else {
         if (flip_dist_solve(d, FLIP_SOLVE_DIVERGENCE, dt, o->tol, o->max_iter, o->precond, &info[0])) return 1;   // :505
         DIST_FLIP(flip_project_velocity(c, dt));              // :507
@@ -486,6 +502,7 @@ extern "C" int flip_dist_substep(flip_dist *d, float dt, const flip_dist_step_op
         if (body) DIST_FLIP(flip_constrain_velocity(c, 1));   // :405-408
     }
     DIST_FLIP(flip_update_diff(c));                           // :416
+    DIST_FLIP(flip_side_join(c));
     // :420 transfer_from_grid_to_particles, :426 advectParticles, :429 apply_particle_displacements: one pass, same bits
     DIST_FLIP(flip_update_particles(c, o->flip_pic_ratio, dt, o->advect, o->density_projection));
     return flip_dist_exchange_particles(d, nullptr, nullptr);

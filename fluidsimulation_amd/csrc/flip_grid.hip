@@ -132,21 +132,25 @@ extern "C" int flip_face_fractions(flip_ctx *ctx) {
     const GridDims g = flip_dims(ctx);
     const int nb = flip_grid_blocks(ctx->B);
     hipStream_t st = ctx->stream;
+    // The solid and the rigid body's fractions go to the back buffers, which then become the front ones: a stage enqueued
+    // earlier on the context's other stream (flip_side_select) keeps reading the previous substep's values undisturbed.
     if (ctx->has_obj) { // SolidObject::compute_face_fractions: mask from the body's own level set
         k_weight_seed<<<nb, FLIP_BLOCK, 0, st>>>(g, ctx->phi_obj, ctx->phi_obj_bg, ctx->seed);
         FLIP_LAUNCH_CHECK();
-        k_face_fractions<<<nb, FLIP_BLOCK, 0, st>>>(g, ctx->phi_obj, ctx->phi_obj_bg, ctx->seed, ctx->owgt[0], ctx->owgt[1],
-                                                   ctx->owgt[2]);
+        k_face_fractions<<<nb, FLIP_BLOCK, 0, st>>>(g, ctx->phi_obj, ctx->phi_obj_bg, ctx->seed, ctx->owgt_back[0], ctx->owgt_back[1],
+                                                   ctx->owgt_back[2]);
         FLIP_LAUNCH_CHECK();
+        for (int a = 0; a < 3; ++a) std::swap(ctx->owgt[a], ctx->owgt_back[a]);
     }
     k_weight_seed<<<nb, FLIP_BLOCK, 0, st>>>(g, ctx->phi_fluid, ctx->g.phi_fluid_bg, ctx->seed);
     FLIP_LAUNCH_CHECK();
     k_face_fractions<<<nb, FLIP_BLOCK, 0, st>>>(g, ctx->phi_fluid, ctx->g.phi_fluid_bg, ctx->seed, ctx->fwgt[0], ctx->fwgt[1],
                                                ctx->fwgt[2]);
     FLIP_LAUNCH_CHECK();
-    k_face_fractions<<<nb, FLIP_BLOCK, 0, st>>>(g, ctx->phi_solid, ctx->g.phi_solid_bg, ctx->seed, ctx->wgt[0], ctx->wgt[1],
-                                               ctx->wgt[2]);
+    k_face_fractions<<<nb, FLIP_BLOCK, 0, st>>>(g, ctx->phi_solid, ctx->g.phi_solid_bg, ctx->seed, ctx->wgt_back[0], ctx->wgt_back[1],
+                                               ctx->wgt_back[2]);
     FLIP_LAUNCH_CHECK();
+    for (int a = 0; a < 3; ++a) std::swap(ctx->wgt[a], ctx->wgt_back[a]);
     k_combine_weights<<<nb, FLIP_BLOCK, 0, st>>>(ctx->B, ctx->wgt[0], ctx->wgt[1], ctx->wgt[2], ctx->owgt[0], ctx->owgt[1],
                                                 ctx->owgt[2], ctx->has_obj ? 1 : 0);
     FLIP_LAUNCH_CHECK();

@@ -167,6 +167,9 @@ struct flip_ctx {
     double *vel[4][3] = {};         // 0 front, 1 back, 2 prev, 3 diff
     double *disp[3] = {};
     float *wgt[3] = {}, *fwgt[3] = {}, *owgt[3] = {};
+    // flip_face_fractions writes these and swaps them with wgt / owgt, so that a stage enqueued before it on the other
+    // stream (constrain_velocity, the labels) still reads the fractions of the previous substep
+    float *wgt_back[3] = {}, *owgt_back[3] = {};
     float *density = nullptr;
     uint8_t *valid[2][3] = {};      // front / back
     uint8_t *active = nullptr, *active_back = nullptr;
@@ -260,12 +263,19 @@ struct flip_ctx {
     bool pair_on = false;
     int pair_slot = 0;              // which set is the active one (0: the set that was active at flip_pair_begin)
     hipStream_t pair_main_stream = nullptr;   // the context's stream while ctx->stream points at a pair stream
+
+    // ---- flip_side_fork / select / join: a second stream for the stages of a substep that do not depend on each other ----
+    bool side_enabled = true;       // flip_set_side_stream
+    bool side_forked = false, side_selected = false;
+    hipStream_t side_stream = nullptr, side_main_stream = nullptr;
+    hipEvent_t side_event[2] = { nullptr, nullptr };
 };
 
 int flip_default_gather_mode();            // FLIP_GATHER_TILE
 int flip_alloc_system(flip_ctx *ctx);      // the active system's arrays (used for both sets)
 void flip_free_system(flip_ctx *ctx);
 void flip_swap_systems(flip_ctx *ctx);     // active <-> other
+int flip_pair_streams(flip_ctx *ctx);      // creates the two solver streams and their events if need be
 int flip_mg_setup(flip_ctx *ctx);   // coarse operators of the assembled system
 int flip_mg_vcycle(flip_ctx *ctx, bool pre_smoothed = false);  // z = M^-1 r and the r.z partials; pre_smoothed: level 0's
                                                                // pre-smoothing has been done by k_pcg_update_pre

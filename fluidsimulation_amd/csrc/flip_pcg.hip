@@ -946,7 +946,7 @@ __global__ void k_set_scalars(flip_pcg_scalars *dst, flip_pcg_scalars v) { *dst 
 //   pcg_prepare  validation, scalars, zeroed vectors, coarse operators, r = b, z = M^-1 r
 //   pcg_batch    `batch` iterations (direction, update, V-cycle) enqueued on ctx->stream
 //   pcg_finish   dependent rows, counters, timings
-static int pair_streams(flip_ctx *ctx) {
+int flip_pair_streams(flip_ctx *ctx) {
     for (int q = 0; q < 2; ++q)
         if (!ctx->pair_stream[q]) FLIP_CHECK(hipStreamCreateWithFlags(&ctx->pair_stream[q], hipStreamNonBlocking));
     for (int q = 0; q < 3; ++q)
@@ -1196,7 +1196,7 @@ extern "C" int flip_pcg_solve(flip_ctx *ctx, double tol, int32_t max_iter, int p
     // the iterations run on a stream of the library's own (the caller's may be the null stream, which cannot be
     // captured into a graph), ordered after everything enqueued so far
     hipStream_t main_stream = ctx->stream;
-    if (int rc = pair_streams(ctx)) return rc;
+    if (int rc = flip_pair_streams(ctx)) return rc;
     hipStream_t st = ctx->pair_stream[0];
     FLIP_CHECK(hipEventRecord(ctx->pair_event[2], main_stream));
     FLIP_CHECK(hipStreamWaitEvent(st, ctx->pair_event[2], 0));
@@ -1251,7 +1251,7 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
     FLIP_REQUIRE(!ctx->pair_on, "flip_solve_pair: not between flip_pair_begin and flip_pair_end");
     FLIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t main_stream = ctx->stream;
-    if (int rc0 = pair_streams(ctx)) return rc0;
+    if (int rc0 = flip_pair_streams(ctx)) return rc0;
     if (int rc0 = ensure_other_set(ctx)) return rc0;
     // The density system lives in the other set, the divergence system in the active one.  Assembly and solver set-up of
     // each (coarse operators, row lists: several dozen small launches) already run on the solve's own stream, side by
@@ -1372,7 +1372,7 @@ extern "C" int flip_pair_begin(flip_ctx *ctx) {
     FLIP_REQUIRE(ctx, "null context");
     FLIP_REQUIRE(!ctx->pair_on, "flip_pair_begin: already begun");
     FLIP_CHECK(hipSetDevice(ctx->device));
-    if (int rc = pair_streams(ctx)) return rc;
+    if (int rc = flip_pair_streams(ctx)) return rc;
     if (int rc = ensure_other_set(ctx)) return rc;
     if (ctx->dist_sums) {   // a slab context: the second set needs the slab solve's arrays too
         flip_swap_systems(ctx);

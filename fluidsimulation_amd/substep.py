@@ -41,29 +41,45 @@ class FlipSubstep:
                 self.ctx.constrain_velocity(True) # :358-361 / :405-408
 
     def step(self, dt: float) -> dict:
+        try:
+            return self._step(dt)
+        finally:
+            self.ctx.side_join()   # a failed call must not leave the context on its side stream
+
+    def _step(self, dt: float) -> dict:
         c = self.ctx
         c.bin_particles(want_outside=False)
         if self.levelset_radius is not None:
             c.fluid_levelset_from_particles(self.levelset_radius)   # :324
+        # the labels and the face fractions do not depend on the velocity chain: they go to the context's second stream
+        c.side_fork()
+        c.side_select(True)
+        c.index_cells(want_count=False)           # :486  (weights of the previous substep)
+        c.side_select(False)
         c.p2g()                                   # :337
         c.mark_valid_from_active()                # :343-345
         c.extrapolate(2)                          # :349
         self._constrain()
+        c.side_select(True)
+        c.face_fractions()                        # :488  (writes the other buffer: the calls above keep the old values)
+        c.side_select(False)
         c.update_prev()                           # :367
         c.add_forces(dt)                          # :373
-        c.index_cells()                           # :486  (weights of the previous substep)
-        c.face_fractions()                        # :488
         c.density(want_count=False)               # :491
+        c.side_join()
         if self.redistribute_seed is not None:
             c.redistribute_overdense(self.redistribute_seed + self.substeps)   # src/Functors.cpp:268-322, inside :491
         self.substeps += 1
         info_den = None
         if self.concurrent_solves:
             info_div, info_den = c.solve_pair(dt, self.tol, self.max_iter, self.precond)   # :505 and :521
-            c.project_velocity(dt)                # :507
+            c.side_fork()
+            c.side_select(True)
             c.select_system(SOLVE_DENSITY)
             c.project_displacement(dt)            # :523
             c.select_system(SOLVE_DIVERGENCE)
+            c.side_select(False)
+            c.project_velocity(dt)                # :507
         else:
             c.build_system(SOLVE_DIVERGENCE, dt)  # :505
             info_div = c.pcg_solve(self.tol, self.max_iter, self.precond)
@@ -75,6 +91,7 @@ class FlipSubstep:
         c.extrapolate(2)                          # :398
         self._constrain()
         c.update_diff()                           # :416
+        c.side_join()
         if self.fused_particle_update:
             c.update_particles(self.ratio, dt, self.advect, self.density_projection)   # :420, :426, :429 in one pass
         else:

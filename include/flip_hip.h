@@ -306,6 +306,25 @@ int flip_select_system(flip_ctx *ctx, int kind);
 int flip_pair_begin(flip_ctx *ctx);
 int flip_pair_select(flip_ctx *ctx, int slot);
 int flip_pair_end(flip_ctx *ctx);
+/* A second stream inside a substep (no counterpart in the reference, whose stages run one after the other on the
+ * CPU's thread pool).  Two chains of src/FluidSimulator.cpp:307-446 do not depend on each other once the fluid level
+ * set exists: (a) flip_p2g, flip_mark_valid_from_active, flip_extrapolate, flip_constrain_velocity, flip_update_prev,
+ * flip_add_forces (:337-:373; they read the level sets, the particles and the face fractions of the PREVIOUS substep and
+ * write velocities, masks and the density) and (b) flip_index_cells, flip_face_fractions (:486-:488; they read the
+ * level sets and the previous fractions and write labels, row indices and the new fractions); after the solves,
+ * flip_project_displacement is independent of flip_project_velocity, flip_extrapolate, flip_constrain_velocity and
+ * flip_update_diff.  flip_side_fork orders the side stream after everything enqueued on the context's stream so far;
+ * between flip_side_select(ctx, 1) and flip_side_select(ctx, 0) every entry point enqueues on the side stream;
+ * flip_side_join orders the context's stream after the side work and selects it.  flip_face_fractions writes the
+ * other buffer of a double-buffered pair, so on whichever stream it runs, flip_constrain_velocity and flip_index_cells
+ * calls made BEFORE it (in host order) read the previous substep's fractions, as the reference's order has it.  The
+ * caller is responsible for putting only independent stages on the two streams.  flip_set_side_stream(ctx, 0) turns
+ * the three calls into no-ops (everything stays on the one stream; the default is on).  Results are the same bits
+ * either way. */
+int flip_set_side_stream(flip_ctx *ctx, int enabled);
+int flip_side_fork(flip_ctx *ctx);
+int flip_side_select(flip_ctx *ctx, int side);
+int flip_side_join(flip_ctx *ctx);
 /* y = A x for the assembled system on dense box vectors (parity hook for the SpMV kernel). */
 int flip_apply_operator(flip_ctx *ctx, const double *x_host, double *y_host);
 /* When enabled, flip_pcg_solve brackets a sample of its operator launches with HIP events and

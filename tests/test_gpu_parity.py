@@ -1246,6 +1246,44 @@ def test_the_one_pass_particle_update_is_the_three_calls(advect, displace, body)
     assert np.abs(va - sc.vel).max() > 0 and (not (advect or displace) or np.abs(pa - sc.pos).max() > 0)
 
 
+@pytest.mark.parametrize("body", [False, True])
+def test_two_streams_inside_a_substep_give_the_bits_of_one(body):
+    """flip_side_fork / flip_side_select / flip_side_join put the labels and face fractions beside the velocity chain
+    (P2G, extrapolation, constrain_velocity, forces) and the displacement projection beside the velocity projection.
+    flip_face_fractions writes the other buffer of a pair, so the constrain_velocity and label calls issued before it
+    still read the previous substep's fractions (src/FluidSimulator.cpp:357 runs before :488).  Three whole substeps with
+    the level set rebuilt from the particles, both constrain passes and the advection must end in the same particles,
+    labels, face fractions and velocities as with flip_set_side_stream(ctx, 0), and misuse is refused."""
+    from fluidsimulation_amd import FlipError, FlipSubstep, PRECOND_MULTIGRID
+    sc = scenes.dam_break(32, ppc=4, seed=12)
+    if body:
+        sc = scenes.add_sphere(sc, vel=(0.1, -0.3, 0.05, 0.4, -0.2, 0.3))
+    rng = np.random.default_rng(23)
+    sc.vel = rng.normal(0, 0.4, sc.pos.shape)
+    results = []
+    for two in (False, True):
+        with FlipContext(sc.desc()) as ctx:
+            ctx.upload_scene(sc)
+            ctx.set_side_stream(two)
+            step = FlipSubstep(ctx, precond=PRECOND_MULTIGRID, constrain=True, advect=True, rigid_body=body, concurrent_solves=True,
+                               levelset_radius=1.01 * float(np.float32(sc.dx)) * np.sqrt(3.0) / 2.0)
+            for _ in range(3):
+                step.step(0.002)
+            if two:
+                with pytest.raises(FlipError):
+                    ctx.side_select(True)          # no fork
+                ctx.side_fork()
+                ctx.side_select(True)
+                with pytest.raises(FlipError):
+                    ctx.side_fork()                # while the side stream is selected
+                ctx.side_join()
+            pos, vel = ctx.download_particles()
+            results.append((pos, vel, ctx.download("label"), ctx.download("weight_u"), ctx.download("weight_w"),
+                            ctx.download("vel_u"), ctx.download("vel_v"), ctx.download("disp_y"), ctx.download("phi_fluid")))
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+
+
 def test_pair_region_is_refused_where_it_cannot_work_and_leaves_the_context_as_it_was():
     """flip_pair_begin / flip_pair_select / flip_pair_end hand the two system sets of a context to a caller that interleaves
     two solves itself (the slab driver).  Calls that manage the sets on their own are refused in between, a select without
