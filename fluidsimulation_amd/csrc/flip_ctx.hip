@@ -70,7 +70,14 @@ int flip_alloc_system(flip_ctx *c) {
     for (int a = 0; a < 3; ++a) A(c->term[a], B)
     A(c->flags, B) A(c->diag, B) A(c->invdiag, B) A(c->rhs, B)
     {
-        double **dp[] = { &c->x, &c->r, &c->r2, &c->z, &c->pv[0], &c->pv[1], &c->ap, &c->cg_diag, &c->cg_inv };
+        // the seven solver vectors are one allocation (x first), so that one fill zeroes them all before a solve
+        // (flip_zero_solver_vectors); x - pad is the pointer hipMalloc returned
+        double **vec[] = { &c->x, &c->r, &c->r2, &c->z, &c->pv[0], &c->pv[1], &c->ap };
+        const int64_t span = B + 2 * c->pad;
+        double *slab = nullptr;
+        A(slab, 7 * span)
+        for (int q = 0; q < 7; ++q) *vec[q] = e == hipSuccess ? slab + q * span + c->pad : nullptr;
+        double **dp[] = { &c->cg_diag, &c->cg_inv };
         for (double **q : dp) {
             A(*q, B + 2 * c->pad)
             if (e == hipSuccess) *q += c->pad;
@@ -88,12 +95,22 @@ int flip_alloc_system(flip_ctx *c) {
     return 0;
 }
 
+// x (unless keep_x), r, r2, z, both direction buffers and Ap to zero, pads included, with one fill
+int flip_zero_solver_vectors(flip_ctx *ctx, bool keep_x, hipStream_t st) {
+    const int64_t span = ctx->B + 2 * ctx->pad;
+    double *from = (keep_x ? ctx->r : ctx->x) - ctx->pad;
+    FLIP_CHECK(hipMemsetAsync(from, 0, (size_t)(keep_x ? 6 : 7) * (size_t)span * 8, st));
+    return 0;
+}
+
 void flip_free_system(flip_ctx *c) {
     flip_mg_free(c);
     for (int a = 0; a < 3; ++a) dfree(c->term[a]);
     dfree(c->flags); dfree(c->diag); dfree(c->invdiag); dfree(c->rhs);
     {   // padded solver arrays: the stored pointers are offset by c->pad
-        double **dp[] = { &c->x, &c->r, &c->r2, &c->z, &c->pv[0], &c->pv[1], &c->ap, &c->cg_diag, &c->cg_inv };
+        if (c->x) (void)hipFree(c->x - c->pad);   // the seven vectors are one allocation
+        c->x = c->r = c->r2 = c->z = c->pv[0] = c->pv[1] = c->ap = nullptr;
+        double **dp[] = { &c->cg_diag, &c->cg_inv };
         for (double **q : dp)
             if (*q) { (void)hipFree(*q - c->pad); *q = nullptr; }
         for (int a = 0; a < 3; ++a)

@@ -274,6 +274,7 @@ struct flip_ctx {
 int flip_default_gather_mode();            // FLIP_GATHER_TILE
 int flip_alloc_system(flip_ctx *ctx);      // the active system's arrays (used for both sets)
 void flip_free_system(flip_ctx *ctx);
+int flip_zero_solver_vectors(flip_ctx *ctx, bool keep_x, hipStream_t st);   // one fill: the vectors are one allocation
 void flip_swap_systems(flip_ctx *ctx);     // active <-> other
 int flip_pair_streams(flip_ctx *ctx);      // creates the two solver streams and their events if need be
 int flip_mg_setup(flip_ctx *ctx);   // coarse operators of the assembled system

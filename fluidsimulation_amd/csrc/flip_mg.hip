@@ -487,9 +487,10 @@ __global__ void k_mg_prune(int cnx, int cny, int cnz, long long csy, long long c
     if (J == 0 || inv[cc - csy] == 0.0) cy[cc] = 0.0;
     if (K == 0 || inv[cc - csz] == 0.0) cz[cc] = 0.0;
 }
-__global__ void k_mg_compact(long long B, const int32_t *__restrict__ scan, int32_t *__restrict__ rows) {
+__global__ void k_mg_compact(long long B, const int32_t *__restrict__ scan, int32_t *__restrict__ rows, int32_t *__restrict__ n_rows) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= B) return;
+    if (c == 0) *n_rows = scan[B];
     if (scan[c + 1] > scan[c]) rows[scan[c]] = (int32_t)c;
 }
 
@@ -523,9 +524,10 @@ static hipError_t mg_alloc_padded(double **p, int64_t n, int64_t pad) {
 void flip_mg_free(flip_ctx *ctx) {
     if (ctx->mg_diag_f) { (void)hipFree(ctx->mg_diag_f - ctx->pad); ctx->mg_diag_f = ctx->mg_inv_f = nullptr; }
     for (flip_mg_level &L : ctx->mg) {
-        double **dp[] = { &L.cx, &L.cy, &L.cz, &L.diag, &L.inv, &L.x, &L.b, &L.t };
+        double **dp[] = { &L.cx, &L.cy, &L.cz, &L.diag, &L.inv, &L.x };   // x, b, t are one allocation
         for (double **q : dp)
             if (*q) { (void)hipFree(*q - L.pad); *q = nullptr; }
+        L.b = L.t = nullptr;
         float **fp[] = { &L.cx_f, &L.cy_f, &L.cz_f, &L.diag_f, &L.inv_f };
         for (float **q : fp)
             if (*q) { (void)hipFree(*q - L.pad); *q = nullptr; }
@@ -562,9 +564,17 @@ static int mg_ensure_levels(flip_ctx *ctx) {
         L.B = (int64_t)nx * ny * nz;
         L.pad = (((int64_t)nx * ny + FLIP_BLOCK + 63) / 64) * 64;
         hipError_t e = hipSuccess;
-        double **dp[] = { &L.cx, &L.cy, &L.cz, &L.diag, &L.inv, &L.x, &L.b, &L.t };
+        double **dp[] = { &L.cx, &L.cy, &L.cz, &L.diag, &L.inv };
         for (double **q : dp)
             if (e == hipSuccess) e = mg_alloc_padded(q, L.B, L.pad);
+        if (e == hipSuccess) {   // the level's three vectors in one allocation: one fill zeroes them before a solve
+            const int64_t span = L.B + 2 * L.pad;
+            e = hipMalloc((void **)&L.x, (size_t)(3 * span) * sizeof(double));
+            if (e == hipSuccess) {
+                e = flip_zero_new(L.x, (size_t)(3 * span) * sizeof(double));
+                L.x += L.pad; L.b = L.x + span; L.t = L.b + span;
+            }
+        }
         if (L.B > mg_dense_cells() && !getenv("FLIP_MG_WIDE_LEVELS")) {
             float **fp[] = { &L.cx_f, &L.cy_f, &L.cz_f, &L.diag_f, &L.inv_f };
             for (float **q : fp)
@@ -644,17 +654,14 @@ static int mg_coarsen_into(flip_ctx *ctx, const MgDev<CT> &F, const double *fine
     k_mg_prune<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.nx, S.ny, S.nz, csy, csz, S.inv, S.cx, S.cy, S.cz);
     FLIP_LAUNCH_CHECK();
     if (int rc = flip_exclusive_scan(ctx, S.scan, S.B + 1)) return rc;
-    k_mg_compact<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.B, S.scan, S.rows);
+    k_mg_compact<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.B, S.scan, S.rows, S.n_rows);
     FLIP_LAUNCH_CHECK();
-    if (int rc = flip_copy_i32(ctx, S.n_rows, S.scan + S.B, st)) return rc;
     if (S.cx_f) {
         k_mg_narrow_level<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.B, S.cx, S.cy, S.cz, S.diag, S.inv, S.cx_f, S.cy_f, S.cz_f, S.diag_f, S.inv_f);
         FLIP_LAUNCH_CHECK();
     }
     // vectors of a previous solve may be non-zero on cells that are no longer rows
-    FLIP_CHECK(hipMemsetAsync(S.x, 0, (size_t)S.B * 8, st));
-    FLIP_CHECK(hipMemsetAsync(S.t, 0, (size_t)S.B * 8, st));
-    FLIP_CHECK(hipMemsetAsync(S.b, 0, (size_t)S.B * 8, st));
+    FLIP_CHECK(hipMemsetAsync(S.x - S.pad, 0, (size_t)(3 * (S.B + 2 * S.pad)) * 8, st));   // x, b, t and their pads
     return 0;
 }
 

@@ -164,13 +164,13 @@ __global__ void k_build_system(BuildArgs A) {
     if (threadIdx.x == 0) A.chunk_flag[blockIdx.x] = any ? 1 : 0;
 }
 
-__global__ void k_compact_chunks(int n_chunks, const int32_t *__restrict__ flag_scan, const int32_t *__restrict__ flag_raw_next,
-                                 int32_t *__restrict__ list) {
+__global__ void k_compact_chunks(int n_chunks, const int32_t *__restrict__ flag_scan, int32_t *__restrict__ list,
+                                 int32_t *__restrict__ count) {
     // flag_scan holds the exclusive scan of the chunk flags over n_chunks+1 entries; chunk q is active
-    // when scan[q+1] > scan[q]
+    // when scan[q+1] > scan[q]; the total goes to *count
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_chunks) return;
-    (void)flag_raw_next;
+    if (q == 0) *count = flag_scan[n_chunks];
     if (flag_scan[q + 1] > flag_scan[q]) list[flag_scan[q]] = q;
 }
 
@@ -182,9 +182,10 @@ __global__ void k_mark_cg_rows(long long B, long long own_lo, long long own_hi, 
     mark[c] = (c >= own_lo && c < own_hi && (flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW) ? 1 : 0;
 }
 __global__ void k_compact_cg_rows(long long B, long long own_lo, long long own_hi, const uint8_t *__restrict__ flags,
-                                  const int32_t *__restrict__ scan, int32_t *__restrict__ rows) {
+                                  const int32_t *__restrict__ scan, int32_t *__restrict__ rows, int32_t *__restrict__ count) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= B) return;
+    if (c == 0) *count = scan[B];
     if (c >= own_lo && c < own_hi && (flags[c] & (FLIP_FLAG_ROW | FLIP_FLAG_DEP)) == FLIP_FLAG_ROW) rows[scan[c]] = (int32_t)c;
 }
 // Slab mode: [reg_lo, reg_hi) are the cells the local preconditioner covers (the owned planes, widened by the
@@ -367,9 +368,8 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
         }
     }
     if (int rc = flip_exclusive_scan(ctx, ctx->chunk_flag, ctx->n_chunks + 1)) return rc;
-    k_compact_chunks<<<flip_grid_blocks(ctx->n_chunks), FLIP_BLOCK, 0, st>>>(ctx->n_chunks, ctx->chunk_flag, nullptr, ctx->chunk_list);
+    k_compact_chunks<<<flip_grid_blocks(ctx->n_chunks), FLIP_BLOCK, 0, st>>>(ctx->n_chunks, ctx->chunk_flag, ctx->chunk_list, ctx->d_counts + 1);
     FLIP_LAUNCH_CHECK();
-    if (int rc = flip_copy_i32(ctx, ctx->d_counts + 1, ctx->chunk_flag + ctx->n_chunks, st)) return rc;
     // compact list of the cells that are rows of the CG system, ascending cell id
     const long long plane = (long long)ctx->g.nx * ctx->g.ny;
     const long long own_lo = ctx->slab_on ? ctx->slab_k0 * plane : 0, own_hi = ctx->slab_on ? ctx->slab_k1 * plane : ctx->B;
@@ -393,9 +393,8 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     k_mark_cg_rows<<<flip_grid_blocks(ctx->B + 1), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan);
     FLIP_LAUNCH_CHECK();
     if (int rc = flip_exclusive_scan(ctx, ctx->cg_scan, ctx->B + 1)) return rc;
-    k_compact_cg_rows<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan, ctx->cg_rows);
+    k_compact_cg_rows<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan, ctx->cg_rows, ctx->d_counts + 6);
     FLIP_LAUNCH_CHECK();
-    if (int rc = flip_copy_i32(ctx, ctx->d_counts + 6, ctx->cg_scan + ctx->B, st)) return rc;
     // rows whose six couplings are the plain face term (1 - 0) * scale
     FLIP_CHECK(hipMemsetAsync(ctx->reg, 0, (size_t)ctx->B, st));
     ctx->reg_value = A.scale;
@@ -990,16 +989,11 @@ static int pcg_prepare(flip_ctx *ctx, double tol, int32_t max_iter, int precond,
     if (warm) {
         k_warm_mask<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, ctx->cg_inv, ctx->x);
         FLIP_LAUNCH_CHECK();
-    } else FLIP_CHECK(hipMemsetAsync(ctx->x, 0, (size_t)ctx->B * 8, st));
-    FLIP_CHECK(hipMemsetAsync(ctx->z, 0, (size_t)ctx->B * 8, st));
-    FLIP_CHECK(hipMemsetAsync(ctx->pv[0], 0, (size_t)ctx->B * 8, st));
-    FLIP_CHECK(hipMemsetAsync(ctx->pv[1], 0, (size_t)ctx->B * 8, st));
-    // the residual buffers are read at the six neighbours of a row; a cell that was a row of an earlier solve must not
-    // hand a stale (possibly non-finite) value to a zero coupling
-    FLIP_CHECK(hipMemsetAsync(ctx->r, 0, (size_t)ctx->B * 8, st));
-    FLIP_CHECK(hipMemsetAsync(ctx->r2, 0, (size_t)ctx->B * 8, st));
+    }
+    // The residual buffers are read at the six neighbours of a row; a cell that was a row of an earlier solve must not
+    // hand a stale (possibly non-finite) value to a zero coupling.  Ap is the V-cycle's scratch on level 0.
+    if (int rc = flip_zero_solver_vectors(ctx, warm, st)) return rc;
     if (use_mg) {
-        FLIP_CHECK(hipMemsetAsync(ctx->ap, 0, (size_t)ctx->B * 8, st)); // V-cycle scratch on level 0
         if (int rc = flip_mg_setup(ctx)) return rc;
         if (ctx->mg.empty()) use_mg = false;
     }
@@ -1555,12 +1549,7 @@ extern "C" int flip_pcg_dist_begin(flip_ctx *ctx, double tol, int32_t max_iter, 
     k_set_scalars<<<1, 1, 0, st>>>(ctx->scal, h); // by value: no host buffer has to outlive the call
     FLIP_LAUNCH_CHECK();
     ctx->x_kind = -1; // the slab solve starts from zero
-    FLIP_CHECK(hipMemsetAsync(ctx->x, 0, (size_t)ctx->B * 8, st));
-    FLIP_CHECK(hipMemsetAsync(ctx->z, 0, (size_t)ctx->B * 8, st));
-    FLIP_CHECK(hipMemsetAsync(ctx->r, 0, (size_t)ctx->B * 8, st));
-    FLIP_CHECK(hipMemsetAsync(ctx->pv[0], 0, (size_t)ctx->B * 8, st));
-    FLIP_CHECK(hipMemsetAsync(ctx->pv[1], 0, (size_t)ctx->B * 8, st));
-    FLIP_CHECK(hipMemsetAsync(ctx->ap, 0, (size_t)ctx->B * 8, st));
+    if (int rc = flip_zero_solver_vectors(ctx, false, st)) return rc;
     bool use_mg = precond == FLIP_PRECOND_MULTIGRID;
     if (use_mg) {
         if (int rc = flip_mg_setup(ctx)) return rc;
