@@ -900,7 +900,11 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_update_pre(PcgArgs A, FusedA
 }
 
 // Back-substitution of the dependent rows: diag x_c = b_c - sum_f A(c,n_f) x_n, x_c = 0 for an all-zero row.
+// CHECKED: only once the solve has stopped (the launch rides behind a batch of iterations, before the host has seen
+// the stop flag).
+template <bool CHECKED>
 __global__ void __launch_bounds__(FLIP_BLOCK) k_pcg_dependent(PcgArgs A) {
+    if (CHECKED && A.scal->done == 0) return;
     int lo, hi;
     d_chunk_range(A, lo, hi);
     for (int q = lo; q < hi; ++q) {
@@ -1135,12 +1139,15 @@ static int pcg_batch_direct(flip_ctx *ctx, PcgRun &run, int batch, bool allow_ev
 // Enqueues the tail of a solve on ctx->stream: dependent rows, end event, read-back of scalars and counters into
 // host memory that must stay alive until the stream has been synchronised; pcg_report then fills `info`.
 struct PcgTail { flip_pcg_scalars h; int32_t counts[8]; };
-static int pcg_enqueue_tail(flip_ctx *ctx, PcgTail &t) {
+// if_done: the dependent rows are substituted only if the stop flag is set by the time the kernel runs; the caller
+// learns that from t.h.done after synchronising and otherwise enqueues the tail again later.
+static int pcg_enqueue_tail(flip_ctx *ctx, PcgTail &t, bool if_done = false) {
     hipStream_t st = ctx->stream;
     PcgArgs A;
     fill_pcg_args(ctx, A);
     if (ctx->sys_eliminated) {
-        k_pcg_dependent<<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(A);
+        if (if_done) k_pcg_dependent<true><<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(A);
+        else k_pcg_dependent<false><<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(A);
         FLIP_LAUNCH_CHECK();
     }
     FLIP_CHECK(hipEventRecord(ctx->events[1], st));
@@ -1255,8 +1262,8 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
     FLIP_CHECK(hipEventRecord(ctx->pair_event[2], main_stream));
     FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[0], ctx->pair_event[2], 0));
     FLIP_CHECK(hipStreamWaitEvent(ctx->pair_stream[1], ctx->pair_event[2], 0));
-    int32_t done[2] = { 0, 0 };
-    bool active[2] = { true, true };
+    bool active[2] = { true, true }, capped[2] = { false, false };
+    PcgTail tail[2];
     // ctx->stream is the stream of whichever system is active; restored before returning
     auto with_system = [&](int q, auto &&fn) -> int {
         if (q == 1) flip_swap_systems(ctx);
@@ -1310,21 +1317,23 @@ extern "C" int flip_solve_pair(flip_ctx *ctx, float dt, double tol, int32_t max_
                     if (!run[q].use_mg || mg_check_after(run[q].launched, expected[q]) || run[q].launched > run[q].max_iter) more = false;
                 }
         }
+        // The look at a solve's stop flag brings its whole tail along -- the substitution of the dependent rows (a launch
+        // that returns at once while the flag is clear), the end event, the scalars and counters -- so that a solve found
+        // stopped needs no second round trip between device and host.
         for (int q = 0; q < 2; ++q)
-            if (active[q]) {
-                const flip_pcg_scalars *sc = q == 0 ? ctx->scal : ctx->other.scal;
-                FLIP_CHECK(hipMemcpyAsync(&done[q], &sc->done, 4, hipMemcpyDeviceToHost, ctx->pair_stream[q]));
-            }
+            if (active[q] && (rc = with_system(q, [&] { return pcg_enqueue_tail(ctx, tail[q], true); }))) return bail(rc);
         for (int q = 0; q < 2; ++q)
             if (active[q]) FLIP_CHECK(hipStreamSynchronize(ctx->pair_stream[q]));
         for (int q = 0; q < 2; ++q)
-            if (active[q] && (done[q] || run[q].launched > run[q].max_iter)) active[q] = false;
+            if (active[q]) {
+                if (tail[q].h.done) active[q] = false;
+                else if (run[q].launched > run[q].max_iter) { active[q] = false; capped[q] = true; }
+            }
     }
-    PcgTail tail[2];
-    for (int q = 0; q < 2; ++q)
-        if ((rc = with_system(q, [&] { return pcg_enqueue_tail(ctx, tail[q]); }))) return bail(rc);
+    for (int q = 0; q < 2; ++q)   // stopped by the iteration limit: the tail without the flag's consent
+        if (capped[q] && (rc = with_system(q, [&] { return pcg_enqueue_tail(ctx, tail[q]); }))) return bail(rc);
     for (int q = 0; q < 2; ++q) {
-        FLIP_CHECK(hipStreamSynchronize(ctx->pair_stream[q]));
+        if (capped[q]) FLIP_CHECK(hipStreamSynchronize(ctx->pair_stream[q]));
         // later work on the context's own stream is ordered after both solves
         FLIP_CHECK(hipEventRecord(ctx->pair_event[q], ctx->pair_stream[q]));
         FLIP_CHECK(hipStreamWaitEvent(main_stream, ctx->pair_event[q], 0));
@@ -1689,7 +1698,7 @@ extern "C" int flip_pcg_dist_finish(flip_ctx *ctx, flip_pcg_info *info) {
     hipStream_t st = ctx->stream;
     PcgArgs A;
     fill_pcg_args(ctx, A);
-    k_pcg_dependent<<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(A);
+    k_pcg_dependent<false><<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(A);
     FLIP_LAUNCH_CHECK();
     FLIP_CHECK(hipEventRecord(ctx->events[1], st));
     flip_pcg_scalars h;
