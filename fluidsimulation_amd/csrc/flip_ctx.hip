@@ -225,8 +225,8 @@ extern "C" int flip_ctx_create(const flip_grid_desc *desc, int device, void *str
         A(c->valid[0][a], B) A(c->valid[1][a], B)
     }
     for (int a = 0; a < 6; ++a) A(c->J[a], B)
-    A(c->density, B) A(c->active, B) A(c->active_back, B) A(c->label, B) A(c->band, B + 16) A(c->seed, B + 16)
-    A(c->tmp_u8, B + 16) A(c->row_index, B + 1)
+    A(c->density, B) A(c->active, B) A(c->active_back, B) A(c->label, B) A(c->band, B) A(c->seed, B)
+    A(c->tmp_u8, B) A(c->row_index, B + 1)
     {
         const int64_t plane = (int64_t)desc->nx * desc->ny;
         c->pad = ((plane + FLIP_BLOCK + 63) / 64) * 64;

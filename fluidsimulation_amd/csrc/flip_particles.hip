@@ -261,56 +261,24 @@ __global__ void k_band_x(GridDims g, const int32_t *__restrict__ cell_start, uin
     }
     out[c] = m;
 }
-// Eight consecutive cells per thread: where they lie in one grid row the five (or 2 reach + 1) neighbour values of all
-// eight are combined bytewise as one 64-bit word each; a neighbour row starts at any byte offset, so its eight bytes are
-// cut out of the two aligned words that hold them (the byte arrays are allocated 16 bytes longer than the box).  A group
-// that straddles a row end takes the cells one by one.
-__device__ __forceinline__ uint64_t d_load_u64_at(const uint8_t *__restrict__ base, long long at) {
-    const uint64_t *w = reinterpret_cast<const uint64_t *>(base) + (at >> 3);
-    const unsigned sh = (unsigned)(at & 7) * 8;
-    const uint64_t lo = w[0];
-    if (sh == 0) return lo;
-    return (lo >> sh) | (w[1] << (64 - sh));
-}
-template <bool BAND>
-__device__ __forceinline__ uint8_t d_dilate_cell(const GridDims &g, long long c, int axis, int reach, const uint8_t *__restrict__ in) {
+__global__ void k_band_axis(GridDims g, int axis, const uint8_t *__restrict__ in, uint8_t *__restrict__ out) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.B) return;
     int i, j, k;
     d_ijk(g, c, i, j, k);
     const int pos = axis == 1 ? j : k, lim = axis == 1 ? g.ny : g.nz;
     const long long stride = axis == 1 ? g.nx : (long long)g.nx * g.ny;
     uint8_t m = 0;
-    for (int d = -reach; d <= reach; ++d) {
+    for (int d = -2; d <= 2; ++d) {
         if (pos + d < 0 || pos + d >= lim) continue;
         const uint8_t v = in[c + d * stride];
-        // bands: bit0 needs distance <= 1 on every axis, bit1 distance <= 2: bit0 of a +-2 neighbour does not count, and
-        // bit1 of any neighbour within 2 does
-        if (!BAND || (d >= -1 && d <= 1)) m |= v;
+        if (d >= -1 && d <= 1) m |= v;
         else m |= (v & 2);
     }
-    return m;
+    // bit0 needs distance <= 1 on every axis, bit1 distance <= 2: bit0 of a +-2 neighbour does not
+    // count, and bit1 of any neighbour within 2 does
+    out[c] = m;
 }
-template <bool BAND>
-__global__ void k_dilate_axis(GridDims g, int axis, int reach, const uint8_t *__restrict__ in, uint8_t *__restrict__ out) {
-    const long long c0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
-    if (c0 >= g.B) return;
-    int i, j, k;
-    d_ijk(g, c0, i, j, k);
-    if (i + 8 <= g.nx) {
-        const int pos = axis == 1 ? j : k, lim = axis == 1 ? g.ny : g.nz;
-        const long long stride = axis == 1 ? g.nx : (long long)g.nx * g.ny;
-        uint64_t m = 0;
-        for (int d = -reach; d <= reach; ++d) {
-            if (pos + d < 0 || pos + d >= lim) continue;
-            const uint64_t v = d_load_u64_at(in, c0 + d * stride);
-            if (!BAND || (d >= -1 && d <= 1)) m |= v;
-            else m |= (v & 0x0202020202020202ULL);
-        }
-        *reinterpret_cast<uint64_t *>(out + c0) = m;
-        return;
-    }
-    for (long long c = c0; c < c0 + 8 && c < g.B; ++c) out[c] = d_dilate_cell<BAND>(g, c, axis, reach, in);
-}
-static inline int flip_dilate_blocks(int64_t B) { return flip_grid_blocks((B + 7) / 8); }
 
 #define GT_T 4 // edge of the LDS-staged gather's tiles in cells (see k_gather_tile)
 static int gather_column();
@@ -434,9 +402,9 @@ extern "C" int flip_bin_particles(flip_ctx *ctx, int64_t *n_outside) {
     ctx->prec_valid = true;
     k_band_x<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, ctx->cell_start, ctx->band);
     FLIP_LAUNCH_CHECK();
-    k_dilate_axis<true><<<flip_dilate_blocks(B), FLIP_BLOCK, 0, st>>>(g, 1, 2, ctx->band, ctx->tmp_u8);
+    k_band_axis<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, 1, ctx->band, ctx->tmp_u8);
     FLIP_LAUNCH_CHECK();
-    k_dilate_axis<true><<<flip_dilate_blocks(B), FLIP_BLOCK, 0, st>>>(g, 2, 2, ctx->tmp_u8, ctx->band);
+    k_band_axis<<<flip_grid_blocks(B), FLIP_BLOCK, 0, st>>>(g, 2, ctx->tmp_u8, ctx->band);
     FLIP_LAUNCH_CHECK();
     if (int rc = build_gather_lists(ctx)) return rc;
     ctx->binned = true;
@@ -1514,6 +1482,19 @@ __global__ void k_near_x(GridDims g, int reach, const int32_t *__restrict__ cell
     const long long row = c - i;
     out[c] = cell_start[row + xb + 1] > cell_start[row + xa] ? 1 : 0;
 }
+__global__ void k_near_axis(GridDims g, int axis, int reach, const uint8_t *__restrict__ in, uint8_t *__restrict__ out) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.B) return;
+    int i, j, k;
+    d_ijk(g, c, i, j, k);
+    const int pos = axis == 1 ? j : k, lim = axis == 1 ? g.ny : g.nz;
+    const long long stride = axis == 1 ? g.nx : (long long)g.nx * g.ny;
+    uint8_t m = 0;
+    for (int d = -reach; d <= reach; ++d)
+        if (pos + d >= 0 && pos + d < lim) m |= in[c + d * stride];
+    out[c] = m;
+}
+
 // One thread owns R cells of a y-column (the kernel is bound by the records it reads, and the shells of neighbouring
 // cells overlap almost entirely).  Shell s of the column is the box [i-s, i+s] x [j0-s, j0+R-1+s] x [k-s, k+s] without
 // the box of shell s-1: after it every particle within Chebyshev distance s of each of the R cells has been visited,
@@ -1666,8 +1647,8 @@ extern "C" int flip_fluid_levelset_from_particles(flip_ctx *ctx, float radius_wo
     const int nb = flip_grid_blocks(ctx->B);
     // scratch: both byte arrays are rewritten by the face-fraction stage before anything reads them
     k_near_x<<<nb, FLIP_BLOCK, 0, ctx->stream>>>(g, reach, ctx->cell_start, ctx->tmp_u8);
-    k_dilate_axis<false><<<flip_dilate_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(g, 1, reach, ctx->tmp_u8, ctx->seed);
-    k_dilate_axis<false><<<flip_dilate_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(g, 2, reach, ctx->seed, ctx->tmp_u8);
+    k_near_axis<<<nb, FLIP_BLOCK, 0, ctx->stream>>>(g, 1, reach, ctx->tmp_u8, ctx->seed);
+    k_near_axis<<<nb, FLIP_BLOCK, 0, ctx->stream>>>(g, 2, reach, ctx->seed, ctx->tmp_u8);
     constexpr int R = 3; // cells per thread in the first pass
     const int nyb = (ctx->g.ny + R - 1) / R;
     if (!ctx->ls_list) FLIP_CHECK(hipMalloc((void **)&ctx->ls_list, (size_t)ctx->B * 4));
