@@ -141,7 +141,7 @@ void flip_swap_systems(flip_ctx *c) {
     std::swap(c->d_counts, o.d_counts); std::swap(c->n_active_chunks, o.n_active_chunks);
     std::swap(c->partial, o.partial); std::swap(c->scal, o.scal);
     c->events.swap(o.events); c->mg.swap(o.mg);
-    std::swap(c->mg_diag_f, o.mg_diag_f); std::swap(c->mg_inv_f, o.mg_inv_f);
+    std::swap(c->mg_diag_f, o.mg_diag_f); std::swap(c->mg_inv_f, o.mg_inv_f); std::swap(c->mg_narrowed, o.mg_narrowed);
     for (int q = 0; q < 2; ++q) { std::swap(c->batch_exec[q], o.batch_exec[q]); std::swap(c->batch_key[q], o.batch_key[q]); }
     std::swap(c->cg_scan, o.cg_scan); std::swap(c->scan_tmp, o.scan_tmp); std::swap(c->scan_tmp_len, o.scan_tmp_len);
     std::swap(c->mg_cz, o.mg_cz); std::swap(c->dist_sums, o.dist_sums); std::swap(c->dist_active, o.dist_active);

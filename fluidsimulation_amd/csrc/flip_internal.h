@@ -100,6 +100,7 @@ struct flip_system_set {
     flip_pcg_scalars *scal = nullptr;
     std::vector<hipEvent_t> events;
     std::vector<flip_mg_level> mg;
+    bool mg_narrowed = false;       // the assembly has written mg_diag_f / mg_inv_f for the system at hand
     float *mg_diag_f = nullptr, *mg_inv_f = nullptr;
     hipGraphExec_t batch_exec[2] = { nullptr, nullptr };
     uint64_t batch_key[2] = { 0, 0 };
@@ -230,6 +231,7 @@ struct flip_ctx {
     bool kprof_arm = false, kprof_valid = false;
     std::vector<flip_mg_level> mg;  // coarse levels, finest first
     float *mg_diag_f = nullptr, *mg_inv_f = nullptr; // float copies of cg_diag / cg_inv for the V-cycle's level 0 (one allocation)
+    bool mg_narrowed = false;       // the assembly has written mg_diag_f / mg_inv_f for the system at hand
     // one batch of solver iterations as an instantiated graph (the kernels' arguments do not change from solve to
     // solve; batch_key says which arguments it was captured with); [0] the long batch, [1] the short one used near the
     // expected end of a solve

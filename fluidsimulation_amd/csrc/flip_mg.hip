@@ -440,11 +440,15 @@ __global__ void __launch_bounds__(FLIP_BLOCK) k_mg_restrict_dense(MgDev<double> 
 template <class CT>
 __global__ void k_mg_coarsen(MgDev<CT> F, const double *__restrict__ fine_diag, int cnx, int cny, int cnz, long long csy, long long csz, double *__restrict__ cx,
                              double *__restrict__ cy, double *__restrict__ cz, double *__restrict__ diag,
-                             double *__restrict__ inv, int32_t *__restrict__ mark) {
+                             double *__restrict__ inv, int32_t *__restrict__ mark, double *__restrict__ vx, double *__restrict__ vb,
+                             double *__restrict__ vt) {
     const long long cB = (long long)cnx * cny * cnz;
     const long long cc = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (cc > cB) return;
     if (cc == cB) { mark[cc] = 0; return; }
+    // the level's vectors start a solve at zero (a previous solve may have left values on cells that are no rows now;
+    // their pads are never written)
+    vx[cc] = 0.0; vb[cc] = 0.0; vt[cc] = 0.0;
     const int I = (int)(cc % cnx);
     const long long tq = cc / cnx;
     const int J = (int)(tq % cny), K = (int)(tq / cny);
@@ -487,11 +491,20 @@ __global__ void k_mg_prune(int cnx, int cny, int cnz, long long csy, long long c
     if (J == 0 || inv[cc - csy] == 0.0) cy[cc] = 0.0;
     if (K == 0 || inv[cc - csz] == 0.0) cz[cc] = 0.0;
 }
-__global__ void k_mg_compact(long long B, const int32_t *__restrict__ scan, int32_t *__restrict__ rows, int32_t *__restrict__ n_rows) {
+// The row list of a level from the scan of its marks, the row count, and (where the level has them: cx_f != null) the
+// float copies of its pruned operator.
+__global__ void k_mg_compact(long long B, const int32_t *__restrict__ scan, int32_t *__restrict__ rows, int32_t *__restrict__ n_rows,
+                             const double *__restrict__ cx, const double *__restrict__ cy, const double *__restrict__ cz,
+                             const double *__restrict__ diag, const double *__restrict__ inv, float *__restrict__ cx_f,
+                             float *__restrict__ cy_f, float *__restrict__ cz_f, float *__restrict__ diag_f, float *__restrict__ inv_f) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= B) return;
     if (c == 0) *n_rows = scan[B];
     if (scan[c + 1] > scan[c]) rows[scan[c]] = (int32_t)c;
+    if (cx_f) {
+        cx_f[c] = (float)cx[c]; cy_f[c] = (float)cy[c]; cz_f[c] = (float)cz[c];
+        diag_f[c] = (float)diag[c]; inv_f[c] = (float)inv[c];
+    }
 }
 
 __global__ void k_mg_narrow(long long B, const double *__restrict__ diag, const double *__restrict__ inv, float *__restrict__ diag_f,
@@ -500,15 +513,6 @@ __global__ void k_mg_narrow(long long B, const double *__restrict__ diag, const 
     if (c >= B) return;
     diag_f[c] = (float)diag[c];
     inv_f[c] = (float)inv[c];
-}
-
-__global__ void k_mg_narrow_level(long long B, const double *__restrict__ cx, const double *__restrict__ cy, const double *__restrict__ cz,
-                                  const double *__restrict__ diag, const double *__restrict__ inv, float *__restrict__ cx_f,
-                                  float *__restrict__ cy_f, float *__restrict__ cz_f, float *__restrict__ diag_f, float *__restrict__ inv_f) {
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= B) return;
-    cx_f[c] = (float)cx[c]; cy_f[c] = (float)cy[c]; cz_f[c] = (float)cz[c];
-    diag_f[c] = (float)diag[c]; inv_f[c] = (float)inv[c];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -649,19 +653,14 @@ static int mg_coarsen_into(flip_ctx *ctx, const MgDev<CT> &F, const double *fine
     hipStream_t st = ctx->stream;
     const long long csy = S.nx, csz = (long long)S.nx * S.ny;
     k_mg_coarsen<CT><<<flip_grid_blocks(S.B + 1), FLIP_BLOCK, 0, st>>>(F, fine_diag, S.nx, S.ny, S.nz, csy, csz, S.cx, S.cy, S.cz, S.diag,
-                                                                      S.inv, S.scan);
+                                                                      S.inv, S.scan, S.x, S.b, S.t);
     FLIP_LAUNCH_CHECK();
     k_mg_prune<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.nx, S.ny, S.nz, csy, csz, S.inv, S.cx, S.cy, S.cz);
     FLIP_LAUNCH_CHECK();
     if (int rc = flip_exclusive_scan(ctx, S.scan, S.B + 1)) return rc;
-    k_mg_compact<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.B, S.scan, S.rows, S.n_rows);
+    k_mg_compact<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.B, S.scan, S.rows, S.n_rows, S.cx, S.cy, S.cz, S.diag, S.inv, S.cx_f, S.cy_f,
+                                                              S.cz_f, S.diag_f, S.inv_f);
     FLIP_LAUNCH_CHECK();
-    if (S.cx_f) {
-        k_mg_narrow_level<<<flip_grid_blocks(S.B), FLIP_BLOCK, 0, st>>>(S.B, S.cx, S.cy, S.cz, S.diag, S.inv, S.cx_f, S.cy_f, S.cz_f, S.diag_f, S.inv_f);
-        FLIP_LAUNCH_CHECK();
-    }
-    // vectors of a previous solve may be non-zero on cells that are no longer rows
-    FLIP_CHECK(hipMemsetAsync(S.x - S.pad, 0, (size_t)(3 * (S.B + 2 * S.pad)) * 8, st));   // x, b, t and their pads
     return 0;
 }
 
@@ -681,8 +680,10 @@ int flip_mg_setup(flip_ctx *ctx) {
         ctx->mg_diag_f = base + ctx->pad;
         ctx->mg_inv_f = base + (ctx->B + 2 * ctx->pad) + ctx->pad;
     }
-    k_mg_narrow<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(ctx->B, ctx->cg_diag, ctx->cg_inv, ctx->mg_diag_f, ctx->mg_inv_f);
-    FLIP_LAUNCH_CHECK();
+    if (!ctx->mg_narrowed) {   // otherwise k_build_system has written them along with the doubles
+        k_mg_narrow<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, ctx->stream>>>(ctx->B, ctx->cg_diag, ctx->cg_inv, ctx->mg_diag_f, ctx->mg_inv_f);
+        FLIP_LAUNCH_CHECK();
+    }
     if (int rc = mg_coarsen_into(ctx, mg_level0(ctx), ctx->cg_diag, ctx->mg[0])) return rc;
     for (size_t l = 1; l < ctx->mg.size(); ++l)
         if (int rc = mg_coarsen_into(ctx, mg_level(ctx->mg[l - 1]), ctx->mg[l - 1].diag, ctx->mg[l])) return rc;

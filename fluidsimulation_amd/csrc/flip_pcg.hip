@@ -45,6 +45,13 @@ struct BuildArgs {
     const float *ou, *ov, *ow;
     double com[3], minv[6], vel[6];
     double *J[6];
+    // by-products for the solver's set-up, each a launch of its own otherwise: the mark of the CG rows among the planes
+    // [own_lo, own_hi) this context owns (input of the row list's scan), the cleared "regular row" bytes, and the float
+    // copies of the CG diagonal and its inverse (null on a slab context, whose diagonal is masked after the assembly)
+    long long own_lo, own_hi;
+    int32_t *cg_mark;
+    uint8_t *reg;
+    float *diag_f, *inv_f;
 };
 
 __global__ void k_build_system(BuildArgs A) {
@@ -143,6 +150,10 @@ __global__ void k_build_system(BuildArgs A) {
         A.cgz[c] = (cg && (fl & 16)) ? (1 - w_lo[2]) * A.scale : 0.f;
         A.cg_diag[c] = cg ? dg : 0.0;
         A.cg_inv[c] = cg ? inv : 0.0;
+        A.cg_mark[c] = (cg && c >= A.own_lo && c < A.own_hi) ? 1 : 0;
+        if (c == 0) A.cg_mark[g.B] = 0;   // terminator of the scan
+        A.reg[c] = 0;
+        if (A.diag_f) { A.diag_f[c] = (float)(cg ? dg : 0.0); A.inv_f[c] = (float)(cg ? inv : 0.0); }
         A.flags[c] = fl;
         A.diag[c] = dg;
         A.invdiag[c] = inv;
@@ -347,6 +358,16 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     A.ou = ctx->owgt[0]; A.ov = ctx->owgt[1]; A.ow = ctx->owgt[2];
     for (int a = 0; a < 3; ++a) A.com[a] = ctx->obj_com[a];
     for (int a = 0; a < 6; ++a) { A.minv[a] = ctx->obj_minv[a]; A.vel[a] = ctx->obj_vel[a]; A.J[a] = ctx->J[a]; }
+    const long long plane = (long long)ctx->g.nx * ctx->g.ny;
+    const long long own_lo = ctx->slab_on ? ctx->slab_k0 * plane : 0, own_hi = ctx->slab_on ? ctx->slab_k1 * plane : ctx->B;
+    A.own_lo = own_lo; A.own_hi = own_hi;
+    A.cg_mark = ctx->cg_scan;
+    A.reg = ctx->reg;
+    // float copies of the diagonal for the V-cycle's level 0, once they exist (flip_mg_setup allocates them and fills them
+    // itself the first time, and always on a slab context)
+    A.diag_f = ctx->slab_on ? nullptr : ctx->mg_diag_f;
+    A.inv_f = ctx->slab_on ? nullptr : ctx->mg_inv_f;
+    ctx->mg_narrowed = A.diag_f != nullptr;
     FLIP_CHECK(hipMemsetAsync(ctx->chunk_flag + ctx->n_chunks, 0, 4, st));
     FLIP_CHECK(hipMemsetAsync(ctx->d_counts + 4, 0, 8, st));
     k_build_system<<<ctx->n_chunks, FLIP_BLOCK, 0, st>>>(A);
@@ -371,8 +392,7 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
     k_compact_chunks<<<flip_grid_blocks(ctx->n_chunks), FLIP_BLOCK, 0, st>>>(ctx->n_chunks, ctx->chunk_flag, ctx->chunk_list, ctx->d_counts + 1);
     FLIP_LAUNCH_CHECK();
     // compact list of the cells that are rows of the CG system, ascending cell id
-    const long long plane = (long long)ctx->g.nx * ctx->g.ny;
-    const long long own_lo = ctx->slab_on ? ctx->slab_k0 * plane : 0, own_hi = ctx->slab_on ? ctx->slab_k1 * plane : ctx->B;
+    bool marked = true;   // k_build_system has left the marks in cg_scan
     if (ctx->slab_on) {
         const int ov = ctx->slab_overlap;
         const long long reg_lo = (ctx->slab_k0 > ov ? ctx->slab_k0 - ov : 0) * plane;
@@ -388,15 +408,17 @@ extern "C" int flip_build_system(flip_ctx *ctx, int kind, float dt) {
             k_compact_region_rows<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, ctx->cg_scan, ctx->mg_rows);
             FLIP_LAUNCH_CHECK();
             if (int rc = flip_copy_i32(ctx, ctx->d_counts + 7, ctx->cg_scan + ctx->B, st)) return rc;
+            marked = false;   // the region's row list went through cg_scan
         }
     }
-    k_mark_cg_rows<<<flip_grid_blocks(ctx->B + 1), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan);
-    FLIP_LAUNCH_CHECK();
+    if (!marked) {
+        k_mark_cg_rows<<<flip_grid_blocks(ctx->B + 1), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan);
+        FLIP_LAUNCH_CHECK();
+    }
     if (int rc = flip_exclusive_scan(ctx, ctx->cg_scan, ctx->B + 1)) return rc;
     k_compact_cg_rows<<<flip_grid_blocks(ctx->B), FLIP_BLOCK, 0, st>>>(ctx->B, own_lo, own_hi, ctx->flags, ctx->cg_scan, ctx->cg_rows, ctx->d_counts + 6);
     FLIP_LAUNCH_CHECK();
-    // rows whose six couplings are the plain face term (1 - 0) * scale
-    FLIP_CHECK(hipMemsetAsync(ctx->reg, 0, (size_t)ctx->B, st));
+    // rows whose six couplings are the plain face term (1 - 0) * scale (k_build_system has cleared the bytes)
     ctx->reg_value = A.scale;
     if (A.eliminate && !ctx->slab_on) {
         k_mark_regular<<<ctx->pcg_blocks, FLIP_BLOCK, 0, st>>>(ctx->cg_rows, ctx->d_counts + 6, ctx->g.nx, plane, A.scale, ctx->cg_c[0],
