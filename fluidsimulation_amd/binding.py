@@ -65,7 +65,7 @@ EXPORTS = [
     "flip_apply_displacements", "flip_advect_particles", "flip_constrain_velocity", "flip_fluid_levelset_from_particles", "flip_mark_valid_from_active", "flip_extrapolate", "flip_add_forces",
     "flip_update_prev", "flip_update_diff", "flip_swap_velocity_buffers", "flip_swap_valid_masks", "flip_velocity_max", "flip_velocity_max_static", "flip_index_cells", "flip_face_fractions",
     "flip_density", "flip_redistribute_overdense", "flip_solid_object_set", "flip_solid_object_velocity", "flip_build_system",
-    "flip_update_particles", "flip_set_system_options", "flip_set_warm_start", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_pair_begin", "flip_pair_select", "flip_pair_end", "flip_set_side_stream", "flip_side_fork", "flip_side_select", "flip_side_join", "flip_project_velocity",
+    "flip_update_particles", "flip_set_system_options", "flip_set_warm_start", "flip_system_download", "flip_pcg_solve", "flip_apply_operator", "flip_scan_i32", "flip_set_profiling", "flip_solver_kernel_times", "flip_solve_pair", "flip_select_system", "flip_pair_begin", "flip_pair_select", "flip_pair_end", "flip_set_side_stream", "flip_side_fork", "flip_side_select", "flip_side_join", "flip_project_velocity",
     "flip_project_displacement", "flip_set_slab", "flip_solid_coupling_partial", "flip_solid_velocity_apply", "flip_pcg_dist_buffer", "flip_pcg_dist_begin", "flip_pcg_dist_direction",
     "flip_pcg_dist_update", "flip_pcg_dist_status", "flip_pcg_dist_finish", "flip_set_slab_overlap",
     "flip_pcg_dist_precondition", "flip_pcg_dist_combine", "flip_particles_reserve", "flip_particles_pack",
@@ -156,6 +156,7 @@ def load_library(path: str = LIB_PATH):
         "flip_system_download": (C.c_int, [vp, vp, vp, vp]),
         "flip_pcg_solve": (C.c_int, [vp, f64, i32, C.c_int, P(PcgInfo)]),
         "flip_apply_operator": (C.c_int, [vp, vp, vp]),
+        "flip_scan_i32": (C.c_int, [vp, vp, C.c_int64, C.c_int32]),
         "flip_set_profiling": (C.c_int, [vp, C.c_int]),
         "flip_solver_kernel_times": (C.c_int, [vp, P(f64)]),
         "flip_solve_pair": (C.c_int, [vp, f32, f64, i32, C.c_int, P(PcgInfo), P(PcgInfo)]),
@@ -406,6 +407,12 @@ class FlipContext:
         y = np.empty(self.shape, dtype=np.float64)
         self._check(self.lib.flip_apply_operator(self.h, _ptr(x), _ptr(y)))
         return y
+
+    def scan_i32(self, values, offset: int = 0):
+        """Exclusive prefix sum of int32 values by the device scan (parity hook); `offset` shifts the data off a 16-byte boundary."""
+        v = np.ascontiguousarray(values, dtype=np.int32).copy()
+        self._check(self.lib.flip_scan_i32(self.h, _ptr(v), v.size, offset))
+        return v
 
     def solve_pair(self, dt: float, tol: float = 1e-15, max_iter: int = 0, precond: int = PRECOND_JACOBI):
         """Assembles and solves the divergence and the density system side by side; returns their two info dicts."""

@@ -703,3 +703,24 @@ int flip_exclusive_scan(flip_ctx *ctx, int32_t *data, int64_t n) {
     }
     return scan_rec(ctx, data, n, ctx->scan_tmp, ctx->scan_tmp_len);
 }
+
+// The scan on a caller's array (parity hook: the binning, the labels, the row lists and every multigrid level go through
+// flip_exclusive_scan; this runs it on n values of the host array, starting `offset` items into a device buffer so that
+// the path for data that are not 16-byte aligned is reachable).
+extern "C" int flip_scan_i32(flip_ctx *ctx, int32_t *host_values, int64_t n, int32_t offset) {
+    FLIP_REQUIRE(ctx && (host_values || n == 0), "flip_scan_i32: null argument");
+    FLIP_REQUIRE(n >= 0 && offset >= 0 && offset < 4, "flip_scan_i32: bad size or offset");
+    FLIP_CHECK(hipSetDevice(ctx->device));
+    if (n == 0) return 0;
+    int32_t *buf = nullptr;
+    FLIP_CHECK(hipMalloc((void **)&buf, (size_t)(n + 4) * 4));
+    int rc = 0;
+    if (hipMemcpyAsync(buf + offset, host_values, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = flip_fail(ctx, "flip_scan_i32: copy to the device", __FILE__, __LINE__);
+    if (!rc) rc = flip_exclusive_scan(ctx, buf + offset, n);
+    if (!rc && hipMemcpyAsync(host_values, buf + offset, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = flip_fail(ctx, "flip_scan_i32: copy from the device", __FILE__, __LINE__);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = flip_fail(ctx, "flip_scan_i32: synchronise", __FILE__, __LINE__);
+    (void)hipFree(buf);
+    return rc;
+}

@@ -325,6 +325,10 @@ int flip_set_side_stream(flip_ctx *ctx, int enabled);
 int flip_side_fork(flip_ctx *ctx);
 int flip_side_select(flip_ctx *ctx, int side);
 int flip_side_join(flip_ctx *ctx);
+/* Exclusive prefix sum of n int32 values in place (parity hook for the scan behind the binning, the labels, the row
+ * lists and the multigrid levels; no counterpart in the reference, which keeps sparse trees).  The values are placed
+ * `offset` (0..3) items into a device buffer, so that the path for data off a 16-byte boundary can be checked too. */
+int flip_scan_i32(flip_ctx *ctx, int32_t *host_values, int64_t n, int32_t offset);
 /* y = A x for the assembled system on dense box vectors (parity hook for the SpMV kernel). */
 int flip_apply_operator(flip_ctx *ctx, const double *x_host, double *y_host);
 /* When enabled, flip_pcg_solve brackets a sample of its operator launches with HIP events and

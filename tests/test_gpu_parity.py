@@ -1246,6 +1246,20 @@ def test_the_one_pass_particle_update_is_the_three_calls(advect, displace, body)
     assert np.abs(va - sc.vel).max() > 0 and (not (advect or displace) or np.abs(pa - sc.pos).max() > 0)
 
 
+@pytest.mark.parametrize("n", [1, 3, 4, 255, 4095, 4096, 4097, 8191, 1_000_003, 4096 * 4096 + 5])
+def test_device_scan_is_the_exclusive_prefix_sum(n):
+    """The reduce-then-scan behind the binning, the labels, the row lists and the multigrid levels against numpy, at the
+    sizes where its structure changes (one tile of 4096, one level of tile sums, two levels above 16.7 M items), at
+    lengths that are no multiple of four, and with the data off a 16-byte boundary (scalar loads instead of int4)."""
+    rng = np.random.default_rng(n)
+    v = rng.integers(0, 7, size=n, dtype=np.int32)
+    want = np.concatenate(([0], np.cumsum(v[:-1], dtype=np.int64))).astype(np.int32)
+    sc = scenes.cube_drop(8, ppc=1, seed=0)
+    with FlipContext(sc.desc()) as ctx:
+        for offset in (0, 1, 3):
+            assert np.array_equal(ctx.scan_i32(v, offset), want), offset
+
+
 @pytest.mark.parametrize("body", [False, True])
 def test_two_streams_inside_a_substep_give_the_bits_of_one(body):
     """flip_side_fork / flip_side_select / flip_side_join put the labels and face fractions beside the velocity chain
