@@ -26,13 +26,15 @@
 // with theta = (2 + lo)/2, delta = (2 - lo)/2: c1 = 1/theta, rho0 = delta/theta, rho1 = 1/(2 theta/delta - rho0),
 // a2 = rho1 rho0, c2 = 2 rho1/delta.  For lo = 0.5 it damps the interval by 0.22 per application where two Jacobi
 // sweeps with weight 0.8 reach 0.36, at the same two operator applications.  Pre- and post-smoothing use the same
-// polynomial, so the V-cycle stays a symmetric operator.  lo = 0.4 gave the fewest CG iterations on the 256^3 dam
-// break (0.3: 63.7, 0.4: 62, 0.5: 64.3, 0.65: 71, 0.8: 77 per substep; two Jacobi sweeps: 78).
+// polynomial, so the V-cycle stays a symmetric operator.  lo = 0.3 gives the fewest CG iterations on the dam break at
+// a time step within the CFL limit (256^3: 0.25: 51.7, 0.3: 50.9, 0.35: 51.05, 0.4: 51.7, 0.5: 53.7, 0.6: 56.6 per
+// substep; 512^3: 55.3 / 55.7 / 56.3 for 0.3 / 0.35 / 0.4; 128^3: 44.8 / 44.4 / 44.6); with the five times larger
+// step of the earlier rounds it was 0.4 (0.3: 63.7, 0.4: 62, 0.5: 64.3, 0.65: 71, 0.8: 77; two Jacobi sweeps: 78).
 // The lower end of the interval can be overridden with FLIP_MG_LAMBDA_LO for tuning.
 struct MgCheb { double c1, a2, c2; };
 static MgCheb mg_cheb() {
     static MgCheb k = [] {
-        double lo = 0.4;
+        double lo = 0.3;
         if (const char *e = getenv("FLIP_MG_LAMBDA_LO")) { const double v = atof(e); if (v > 0.0 && v < 2.0) lo = v; }
         const double theta = 0.5 * (2.0 + lo), delta = 0.5 * (2.0 - lo);
         const double rho0 = delta / theta, rho1 = 1.0 / (2.0 * theta / delta - rho0);
