@@ -498,7 +498,8 @@ extern "C" int64_t flip_particles_count(const flip_ctx *ctx) { return ctx ? ctx-
 // tried.  The last candidate is kept whatever it measures (the side stream is then merely of no use).
 __global__ void k_spin(long long ticks) {
     const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    // bounded in iterations as well, so that the kernel ends whatever the clock does (some tens of milliseconds at most)
+    for (int it = 0; it < 200000 && wall_clock64() - t0 < ticks; ++it) __builtin_amdgcn_s_sleep(8);
 }
 static int pick_side_stream(flip_ctx *ctx) {
     int rate_khz = 100000;   // wall_clock64 ticks per millisecond
