@@ -67,8 +67,8 @@ LEVELSET_BYTES_PER_PARTICLE, LEVELSET_BYTES_PER_CELL = 24, 8   # read pos; read 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=int(os.environ.get("FLIP_BENCH_N", "256")))
     ap.add_argument("--ppc", type=int, default=8)
     ap.add_argument("--dt", type=float, default=0.001)
