@@ -435,9 +435,12 @@ def main():
         # measured below sees the state the timed run reached.  The work per step does not depend on the velocities.
         saved_state = ctx.download_particles() + (ctx.download_mass(),)
         hstep = FlipSubstep(ctx, tol=args.tol, max_iter=args.max_iter, precond=precond, concurrent_solves=not args.sequential_solves)
-        h_elapsed, _ = timed(hstep, args.steps)
+        # at most 20 steps: without advection the velocities grow without bound, and after some hundred steps the solves
+        # of this leg no longer converge
+        h_steps = min(args.steps, 20)
+        h_elapsed, _ = timed(hstep, h_steps)
         ctx.upload_particles(*saved_state)
-        hot = {"value": args.steps / h_elapsed, "unit": "substeps/s", "ms_per_step": 1e3 * h_elapsed / args.steps,
+        hot = {"value": h_steps / h_elapsed, "unit": "substeps/s", "ms_per_step": 1e3 * h_elapsed / h_steps,
                "what": "binning, P2G + density, extrapolation, forces, labels, face fractions, both solves and projections, G2P, "
                        "displacements; fluid level set as left by the last full step"}
 
